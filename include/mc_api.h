@@ -1,0 +1,168 @@
+/*
+ * mc_api.h -- C ABI of the MI355X metagenomic classifier core (libmcclark.so).
+ *
+ * This is the drop-in boundary for ONE path of ardaicoz/jn_cuclark: the device
+ * manager + kernels behind `class CuClarkDB<HKMERr>` (reference
+ * src/CuClarkDB.cuh:39-153, src/CuClarkDB.cu).  Every entry point below names the
+ * reference member it replaces.  Plain C types only: pointers, sizes, integers.
+ * INTEGRATION.md shows the C++ shim a maintainer drops in place of CuClarkDB.cu.
+ *
+ * Conventions
+ *   - every function returns MC_OK (0) or a negative MC_E* code; the message is
+ *     available from mc_last_error() (thread-local).  Nothing calls exit(): the
+ *     reference's CUERR macro (CuClarkDB.cu:45-53) printed and exited instead.
+ *   - one mc_ctx = one GPU (one HIP device, its streams, one database shard).
+ *     Multi-GPU = one process (or thread) per GPU, each with its own ctx, combined
+ *     with mc_merge_rows_device / mc_result_rows_device after the exchange.
+ *   - HTSIZE and MAXHITS are run-time parameters (the reference compiles two
+ *     binaries, src/parameters.hh:37-48 vs src/parameters_light_hh:38-49).
+ *   - wire types are the reference's: containers/labels/results are uint16_t,
+ *     read offsets uint32_t (src/dataType.hh:37-43).
+ *
+ * Defined behaviour where the reference has none (DESIGN.md "Deviations"):
+ *   a read that hits more than `maxhits` distinct targets keeps the `maxhits`
+ *   SMALLEST target ids (row and final result alike) and is counted in
+ *   mc_stats.reads_over_maxhits; the reference overruns shared memory there
+ *   (CuClarkDB.cu:1140-1151).
+ */
+#ifndef MC_API_H
+#define MC_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_API_VERSION 1
+
+enum {
+    MC_OK          =  0,
+    MC_EINVAL      = -1,   /* bad argument / unsupported parameter combination */
+    MC_EIO         = -2,   /* database files missing or short                  */
+    MC_ENOMEM      = -3,   /* host or device allocation failed                 */
+    MC_EHIP        = -4,   /* HIP runtime error (message has the HIP string)   */
+    MC_ESTATE      = -5,   /* call out of order (e.g. submit before load_db)   */
+    MC_ENODEVICE   = -6    /* no usable gfx950 device                          */
+};
+
+typedef struct mc_ctx mc_ctx;
+
+/* Size of one final result row: [sumN, idxBest+1, best, idxSecond+1, second]
+ * (CuClarkDB.cu:1401-1405, CuCLARK_hh.hh:1592). */
+#define MC_FINAL_ROW 5
+
+/* flags of mc_submit / mc_query_device */
+#define MC_F_FINAL    1u   /* produce the 5-u16 final rows (the fused query+top-2 path) */
+#define MC_F_ROWS     2u   /* produce sparse rows [n, t0,h0, ...] (--extended, shards)  */
+
+typedef struct mc_db_info {
+    uint64_t htsize;          /* total buckets of the table                         */
+    uint64_t shard_begin;     /* first bucket held by this ctx                      */
+    uint64_t shard_end;       /* one past the last bucket held by this ctx          */
+    uint64_t n_keys;          /* k-mers resident on this device                     */
+    uint64_t n_overflow_buckets; /* buckets larger than a line, kept in the side table */
+    uint64_t n_overflow_keys;
+    uint32_t line_bytes;      /* bucket line size chosen at load (64 or 128)         */
+    uint32_t line_capacity;   /* k-mers per line                                     */
+    uint64_t device_bytes;    /* HBM held by the database                            */
+} mc_db_info;
+
+typedef struct mc_stats {
+    uint64_t reads;               /* reads classified since mc_open                  */
+    uint64_t reads_over_maxhits;  /* reads that hit more than maxhits targets        */
+    uint64_t kernel_launches;
+} mc_stats;
+
+const char *mc_last_error(void);
+int mc_api_version(void);
+
+/* Number of gfx950 devices visible.  replaces: cudaGetDeviceCount, CuClarkDB.cu:120 */
+int mc_device_count(int *count);
+
+/* Create a context on `device` (-1 = current HIP device).
+ * replaces: CuClarkDB::CuClarkDB (CuClarkDB.cu:94-241).  k in [2,32] with
+ * (4^k-1)/htsize < 2^32-1 (the reference's 4-byte-key regime, main.cc:267-275, which
+ * covers k=31 full and k=27 light); num_targets = targetsName.size()-1;
+ * maxhits = MAXHITS (15 full / 23 light), at most 63. */
+int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize,
+            uint32_t num_targets, uint32_t maxhits);
+int mc_close(mc_ctx *ctx);
+
+/* Load <base>.sz/.ky/.lb, keep the buckets [shard_begin, shard_end) (0,0 = all),
+ * upload and re-lay them out as bucket lines in HBM.
+ * replaces: CuClarkDB::read + swapDbParts (CuClarkDB.cu:463-815).  key_bytes =
+ * sizeof(HKMERr) of the files (2 or 4).  sampling = the -s factor (<=1: none,
+ * CuClarkDB.cu:490-513).  MC_EIO when a file is missing (the reference returns
+ * false and the caller rebuilds, CuCLARK_hh.hh:622-684). */
+int mc_load_db(mc_ctx *ctx, const char *base, int key_bytes, uint32_t sampling,
+               uint64_t shard_begin, uint64_t shard_end);
+
+/* Same, from the three arrays already in host memory (contents of .sz/.ky/.lb). */
+int mc_load_db_host(mc_ctx *ctx, const uint8_t *sz, const void *keys, int key_bytes,
+                    const uint16_t *labels, uint64_t n_keys,
+                    uint64_t shard_begin, uint64_t shard_end);
+
+/* Same, from arrays already in HBM on ctx's device: d_sz covers buckets
+ * [shard_begin, shard_end) only, d_keys (u32) / d_labels their n_keys elements. */
+int mc_load_db_device(mc_ctx *ctx, const uint8_t *d_sz, const uint32_t *d_keys,
+                      const uint16_t *d_labels, uint64_t n_keys,
+                      uint64_t shard_begin, uint64_t shard_end);
+
+int mc_get_db_info(mc_ctx *ctx, mc_db_info *out);
+int mc_get_stats(mc_ctx *ctx, mc_stats *out);
+
+/* Allocate per-batch pinned input buffers, the result tables and the device
+ * staging buffers.  The library owns all of them.
+ * replaces: CuClarkDB::malloc (CuClarkDB.cu:321-421).  max_reads / max_containers
+ * bound one batch.  want_rows != 0 also allocates sparse-row outputs
+ * (row = 2*maxhits+2 u16, CuCLARK_hh.hh:1586-1589). */
+int mc_alloc_batches(mc_ctx *ctx, uint32_t n_batches, uint64_t max_reads,
+                     uint64_t max_containers, int want_rows);
+
+/* Pinned host pointers of one batch: the caller fills reads_ptr[n_reads+1] and
+ * containers[], and reads final_rows / sparse_rows after mc_wait.  Any out pointer
+ * may be NULL.  (In the reference these come back from malloc, .cuh:112-123.) */
+int mc_batch_buffers(mc_ctx *ctx, uint32_t batch, uint32_t **reads_ptr,
+                     uint16_t **containers, uint16_t **final_rows, uint16_t **sparse_rows);
+
+/* Enqueue one filled batch: H2D, query kernel, D2H, completion event; returns
+ * without waiting.  Batches alternate between two HIP streams so the copies of
+ * one overlap the kernel of the other.
+ * replaces: readyBatch + queryBatch (CuClarkDB.cu:820-987). */
+int mc_submit(mc_ctx *ctx, uint32_t batch, uint64_t n_reads, uint64_t n_containers,
+              uint32_t flags);
+
+/* Block until the batch's results are in its host buffers.
+ * replaces: waitForBatch (CuClarkDB.cu:441-446). */
+int mc_wait(mc_ctx *ctx, uint32_t batch);
+
+/* replaces: sync (CuClarkDB.cu:426-436) */
+int mc_sync(mc_ctx *ctx);
+
+/* replaces: freeBatchMemory (CuClarkDB.cu:284-316) */
+int mc_free_batches(mc_ctx *ctx);
+
+/* ---- device-resident entry points (inputs and outputs already in HBM) -------
+ * `stream` is a hipStream_t (NULL = the ctx's first stream).  Used by the
+ * multi-GPU path (rows travel over RCCL between the calls) and by bench.py. */
+
+/* queryKernel (+ fused resultKernel when MC_F_FINAL): CuClarkDB.cu:999-1254. */
+int mc_query_device(mc_ctx *ctx, const uint32_t *d_reads_ptr, const uint16_t *d_containers,
+                    uint64_t n_reads, uint64_t n_containers, uint32_t flags,
+                    uint16_t *d_final_rows, uint16_t *d_sparse_rows, void *stream);
+
+/* mergeKernel: out = union(a, b) with counts added; out may alias a.
+ * CuClarkDB.cu:1261-1355. */
+int mc_merge_rows_device(mc_ctx *ctx, const uint16_t *d_a, const uint16_t *d_b,
+                         uint64_t n_reads, uint16_t *d_out, void *stream);
+
+/* resultKernel: sparse rows -> final rows.  CuClarkDB.cu:1361-1411. */
+int mc_result_rows_device(mc_ctx *ctx, const uint16_t *d_rows, uint64_t n_reads,
+                          uint16_t *d_final_rows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_API_H */

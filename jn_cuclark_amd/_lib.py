@@ -1,0 +1,83 @@
+"""ctypes binding of libmcclark.so (include/mc_api.h).  Fails loudly when the HIP
+library is missing: there is no CPU fallback anywhere in the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MC_F_FINAL = 1
+MC_F_ROWS = 2
+MC_FINAL_ROW = 5
+
+
+class McError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmcclark error %d: %s" % (code, msg))
+        self.code = code
+
+
+class McDbInfo(C.Structure):
+    _fields_ = [("htsize", C.c_uint64), ("shard_begin", C.c_uint64), ("shard_end", C.c_uint64),
+                ("n_keys", C.c_uint64), ("n_overflow_buckets", C.c_uint64),
+                ("n_overflow_keys", C.c_uint64), ("line_bytes", C.c_uint32),
+                ("line_capacity", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
+class McStats(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("reads_over_maxhits", C.c_uint64),
+                ("kernel_launches", C.c_uint64)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libmcclark.so")
+
+
+# every symbol include/mc_api.h declares: (name, restype, argtypes)
+_vp, _u64, _u32, _i = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+SYMBOLS = [
+    ("mc_last_error", C.c_char_p, []),
+    ("mc_api_version", _i, []),
+    ("mc_device_count", _i, [C.POINTER(_i)]),
+    ("mc_open", _i, [C.POINTER(_vp), _i, _u32, _u64, _u32, _u32]),
+    ("mc_close", _i, [_vp]),
+    ("mc_load_db", _i, [_vp, C.c_char_p, _i, _u32, _u64, _u64]),
+    ("mc_load_db_host", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
+    ("mc_load_db_device", _i, [_vp, _vp, _vp, _vp, _u64, _u64, _u64]),
+    ("mc_get_db_info", _i, [_vp, C.POINTER(McDbInfo)]),
+    ("mc_get_stats", _i, [_vp, C.POINTER(McStats)]),
+    ("mc_alloc_batches", _i, [_vp, _u32, _u64, _u64, _i]),
+    ("mc_batch_buffers", _i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    ("mc_submit", _i, [_vp, _u32, _u64, _u64, _u32]),
+    ("mc_wait", _i, [_vp, _u32]),
+    ("mc_sync", _i, [_vp]),
+    ("mc_free_batches", _i, [_vp]),
+    ("mc_query_device", _i, [_vp, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
+    ("mc_merge_rows_device", _i, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    ("mc_result_rows_device", _i, [_vp, _vp, _u64, _vp, _vp]),
+]
+
+
+def load_library():
+    """Load libmcclark.so and bind every symbol of include/mc_api.h."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s is missing: build it with `make -C jn_cuclark_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no CPU fallback." % path)
+        lib = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)          # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = load_library().mc_last_error()
+        raise McError(rc, msg.decode() if msg else "")

@@ -1,0 +1,641 @@
+// mc_api.hip -- host side of libmcclark.so: context, database load + re-layout,
+// batch buffers, streams, launches.  The C ABI is declared in include/mc_api.h; each
+// function there names the CuClarkDB member it replaces (reference src/CuClarkDB.cu).
+//
+// There is NO CPU fallback in this library: without a gfx950 device every entry point
+// that needs one fails with MC_ENODEVICE / MC_EHIP.
+#include "../../include/mc_api.h"
+#include "mc_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(MC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct Batch {
+    uint32_t *h_ptr = nullptr;
+    uint16_t *h_con = nullptr;
+    uint16_t *h_final = nullptr;
+    uint16_t *h_rows = nullptr;
+    hipEvent_t ev = nullptr;
+    bool submitted = false;
+};
+
+struct Slot {
+    uint32_t *d_ptr = nullptr;
+    uint16_t *d_con = nullptr;
+    uint16_t *d_final = nullptr;
+    uint16_t *d_rows = nullptr;
+};
+
+// libdivide-style magic for unsigned 64-bit division by a run-time constant
+mc::DivU64 make_div(uint64_t d)
+{
+    mc::DivU64 r{};
+    r.d = d;
+    const uint32_t L = 63u - (uint32_t)__builtin_clzll(d);
+    if ((d & (d - 1)) == 0) { r.magic = 0; r.shift = L; r.add = 0; return r; }
+    const unsigned __int128 num = (unsigned __int128)1 << (64 + L);
+    uint64_t m = (uint64_t)(num / d);
+    const uint64_t rem = (uint64_t)(num % d);
+    const uint64_t e = d - rem;
+    if (e < ((uint64_t)1 << L)) {
+        r.shift = L; r.add = 0;
+    } else {
+        m += m;
+        const uint64_t twice = rem + rem;
+        if (twice >= d || twice < rem) m += 1;
+        r.shift = L; r.add = 1;
+    }
+    r.magic = m + 1;
+    return r;
+}
+
+} // namespace
+
+struct mc_ctx {
+    int device = 0;
+    uint32_t k = 0, num_targets = 0, maxhits = 0;
+    uint64_t htsize = 0;
+    mc::DivU64 div{};
+    int n_cu = 0;
+
+    hipStream_t streams[2] = {nullptr, nullptr};
+
+    // database
+    bool db_loaded = false;
+    uint8_t *d_lines = nullptr;
+    uint32_t *d_ovf_keys = nullptr;
+    uint16_t *d_ovf_labels = nullptr;
+    mc_db_info info{};
+    int grid_blocks = 0;
+
+    unsigned long long *d_over = nullptr;
+
+    // batches
+    std::vector<Batch> batches;
+    Slot slots[2];
+    uint64_t max_reads = 0, max_con = 0;
+    bool want_rows = false;
+
+    mc_stats stats{};
+};
+
+namespace {
+
+int set_dev(mc_ctx *c)
+{
+    HIPCHK(hipSetDevice(c->device));
+    return MC_OK;
+}
+
+void free_db(mc_ctx *c)
+{
+    if (c->d_lines) (void)hipFree(c->d_lines);
+    if (c->d_ovf_keys) (void)hipFree(c->d_ovf_keys);
+    if (c->d_ovf_labels) (void)hipFree(c->d_ovf_labels);
+    c->d_lines = nullptr; c->d_ovf_keys = nullptr; c->d_ovf_labels = nullptr;
+    c->db_loaded = false;
+}
+
+template <int LINE>
+int launch_fill(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint16_t *d_labels,
+                uint64_t nb, const uint64_t *d_koff, const uint64_t *d_ooff, uint32_t nblk)
+{
+    hipLaunchKernelGGL(mc::fill_lines_kernel<LINE>, dim3(nblk), dim3(mc::RL_THREADS), 0, c->streams[0],
+                       d_sz, d_keys, d_labels, nb, d_koff, d_ooff, c->d_lines, c->d_ovf_keys, c->d_ovf_labels);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+// Build the bucket lines from raw arrays resident on the device.
+int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint16_t *d_labels,
+             uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
+{
+    const uint64_t nb = shard_end - shard_begin;
+    hipStream_t st = c->streams[0];
+
+    // 1. histogram of bucket sizes -> line size
+    unsigned long long *d_hist = nullptr;
+    HIPCHK(hipMalloc(&d_hist, 256 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), st));
+    {
+        const uint64_t want = (nb + 256 * 64 - 1) / (256 * 64);
+        const uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)c->n_cu * 8));
+        hipLaunchKernelGGL(mc::size_hist_kernel, dim3(g), dim3(256), 0, st, d_sz, nb, d_hist);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned long long hist[256];
+    HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_hist);
+
+    uint64_t total = 0, nonempty = 0;
+    for (int i = 0; i < 256; i++) { total += hist[i] * (uint64_t)i; if (i) nonempty += hist[i]; }
+    if (total != n_keys)
+        return fail(MC_EINVAL, "bucket sizes sum to " + std::to_string(total) + " but n_keys is " + std::to_string(n_keys));
+    auto over = [&](int cap) { uint64_t b = 0; for (int i = cap + 1; i < 256; i++) b += hist[i]; return b; };
+    // 64-byte lines unless more than 3 % of the non-empty buckets would overflow them
+    const char *force = getenv("MC_LINE_BYTES");
+    uint32_t line = (nonempty == 0 || over(mc::LineCfg<64>::CAP) * 100 <= nonempty * 3) ? 64u : 128u;
+    if (force && (atoi(force) == 64 || atoi(force) == 128)) line = (uint32_t)atoi(force);
+    const int cap = line == 64 ? mc::LineCfg<64>::CAP : mc::LineCfg<128>::CAP;
+    uint64_t n_ovf_b = 0, n_ovf_k = 0;
+    for (int i = cap + 1; i < 256; i++) { n_ovf_b += hist[i]; n_ovf_k += hist[i] * (uint64_t)i; }
+
+    // 2. per-workgroup sums -> exclusive offsets (host scan of ~nb/1024 numbers)
+    const uint32_t nblk = (uint32_t)((nb + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    uint32_t *d_bk = nullptr, *d_bo = nullptr;
+    uint64_t *d_koff = nullptr, *d_ooff = nullptr;
+    HIPCHK(hipMalloc(&d_bk, (size_t)nblk * 4));
+    HIPCHK(hipMalloc(&d_bo, (size_t)nblk * 4));
+    hipLaunchKernelGGL(mc::block_sums_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz, nb, (uint32_t)cap, d_bk, d_bo);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> bk(nblk), bo(nblk);
+    HIPCHK(hipMemcpyAsync(bk.data(), d_bk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(bo.data(), d_bo, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_bk); (void)hipFree(d_bo);
+    std::vector<uint64_t> koff(nblk), ooff(nblk);
+    uint64_t ak = 0, ao = 0;
+    for (uint32_t i = 0; i < nblk; i++) { koff[i] = ak; ooff[i] = ao; ak += bk[i]; ao += bo[i]; }
+    if (ak != n_keys || ao != n_ovf_k) return fail(MC_EINVAL, "internal: block sums disagree with histogram");
+    HIPCHK(hipMalloc(&d_koff, (size_t)nblk * 8));
+    HIPCHK(hipMalloc(&d_ooff, (size_t)nblk * 8));
+    HIPCHK(hipMemcpyAsync(d_koff, koff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ooff, ooff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+
+    // 3. allocate and fill the lines
+    free_db(c);
+    const size_t line_bytes = (size_t)nb * line;
+    if (hipMalloc(&c->d_lines, line_bytes ? line_bytes : 16) != hipSuccess) {
+        (void)hipFree(d_koff); (void)hipFree(d_ooff);
+        return fail(MC_ENOMEM, "hipMalloc of " + std::to_string(line_bytes) + " bytes of bucket lines failed");
+    }
+    HIPCHK(hipMalloc(&c->d_ovf_keys, (size_t)(n_ovf_k ? n_ovf_k : 4) * 4));
+    HIPCHK(hipMalloc(&c->d_ovf_labels, (size_t)(n_ovf_k ? n_ovf_k : 4) * 2));
+    int rc = line == 64 ? launch_fill<64>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk)
+                        : launch_fill<128>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk);
+    if (rc != MC_OK) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_koff); (void)hipFree(d_ooff);
+
+    c->info.htsize = c->htsize;
+    c->info.shard_begin = shard_begin;
+    c->info.shard_end = shard_end;
+    c->info.n_keys = n_keys;
+    c->info.n_overflow_buckets = n_ovf_b;
+    c->info.n_overflow_keys = n_ovf_k;
+    c->info.line_bytes = line;
+    c->info.line_capacity = (uint32_t)cap;
+    c->info.device_bytes = line_bytes + n_ovf_k * 6;
+
+    // persistent grid: as many workgroups as stay resident
+    int occ = 0;
+    if (line == 64) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::query_kernel<64>, mc::BLOCK_THREADS, 0));
+    else            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::query_kernel<128>, mc::BLOCK_THREADS, 0));
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+    c->grid_blocks = occ * c->n_cu;
+    c->db_loaded = true;
+    return MC_OK;
+}
+
+int norm_shard(mc_ctx *c, uint64_t &sb, uint64_t &se)
+{
+    if (sb == 0 && se == 0) se = c->htsize;
+    if (sb >= se || se > c->htsize) return fail(MC_EINVAL, "bad shard range");
+    return MC_OK;
+}
+
+bool pread_all(int fd, void *dst, size_t n, uint64_t off)
+{
+    char *p = (char *)dst;
+    while (n) {
+        ssize_t g = pread(fd, p, n, (off_t)off);
+        if (g <= 0) return false;
+        p += g; off += (uint64_t)g; n -= (size_t)g;
+    }
+    return true;
+}
+
+int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads,
+                 uint64_t n_con, uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st)
+{
+    if (n_reads == 0) return MC_OK;
+    mc::QueryArgs a{};
+    a.reads_ptr = d_ptr; a.containers = d_con; a.n_reads = n_reads; a.n_containers = n_con ? n_con : 1;
+    a.lines = c->d_lines; a.ovf_keys = c->d_ovf_keys; a.ovf_labels = c->d_ovf_labels;
+    a.shard_begin = c->info.shard_begin; a.shard_end = c->info.shard_end;
+    a.div = c->div; a.k = c->k; a.maxhits = c->maxhits; a.flags = flags;
+    a.stage_ok = (((uintptr_t)d_con) & 15u) == 0 ? 1u : 0u;
+    a.final_rows = d_final; a.sparse_rows = d_rows; a.over_maxhits = c->d_over;
+    const uint64_t n_groups = (n_reads + mc::GROUP_READS - 1) / mc::GROUP_READS;
+    const uint64_t want = (n_groups + mc::WAVES_PER_BLOCK - 1) / mc::WAVES_PER_BLOCK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->grid_blocks);
+    if (c->info.line_bytes == 64)
+        hipLaunchKernelGGL(mc::query_kernel<64>, dim3(grid), dim3(mc::BLOCK_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL(mc::query_kernel<128>, dim3(grid), dim3(mc::BLOCK_THREADS), 0, st, a);
+    HIPCHK(hipGetLastError());
+    c->stats.reads += n_reads;
+    c->stats.kernel_launches++;
+    return MC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mc_last_error(void) { return g_err.c_str(); }
+int mc_api_version(void) { return MC_API_VERSION; }
+
+int mc_device_count(int *count)
+{
+    if (!count) return fail(MC_EINVAL, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return fail(MC_ENODEVICE, "hipGetDeviceCount failed"); }
+    *count = n;
+    return MC_OK;
+}
+
+int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_targets, uint32_t maxhits)
+{
+    if (!out) return fail(MC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (k < 2 || k > 32) return fail(MC_EINVAL, "k must be in [2,32]");
+    if (htsize < 2) return fail(MC_EINVAL, "htsize must be >= 2");
+    if (maxhits < 1 || maxhits > 63) return fail(MC_EINVAL, "maxhits must be in [1,63]");
+    // 4-byte-key regime: every quotient must be < 0xFFFFFFFF (the line sentinel)
+    const unsigned __int128 maxkmer = k == 32 ? (unsigned __int128)~0ull : (((unsigned __int128)1 << (2 * k)) - 1);
+    if (maxkmer / htsize >= 0xFFFFFFFFull)
+        return fail(MC_EINVAL, "k/htsize combination needs keys wider than 32 bits (reference T64 regime): not supported");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(MC_ENODEVICE, "no HIP device visible");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n) return fail(MC_ENODEVICE, "device index out of range");
+    mc_ctx *c = new mc_ctx();
+    c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
+    c->div = make_div(htsize);
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount; }
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&c->d_over, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_over, 0, sizeof(unsigned long long));
+    if (e != hipSuccess) { delete c; return fail(MC_EHIP, std::string("mc_open: ") + hipGetErrorString(e)); }
+    *out = c;
+    return MC_OK;
+}
+
+int mc_close(mc_ctx *c)
+{
+    if (!c) return MC_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    mc_free_batches(c);
+    free_db(c);
+    if (c->d_over) (void)hipFree(c->d_over);
+    for (int i = 0; i < 2; i++) if (c->streams[i]) (void)hipStreamDestroy(c->streams[i]);
+    delete c;
+    return MC_OK;
+}
+
+int mc_load_db_device(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint16_t *d_labels,
+                      uint64_t n_keys, uint64_t sb, uint64_t se)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    int rc = set_dev(c); if (rc) return rc;
+    rc = norm_shard(c, sb, se); if (rc) return rc;
+    return relayout(c, d_sz, d_keys, d_labels, n_keys, sb, se);
+}
+
+int mc_load_db_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,
+                    uint64_t n_keys, uint64_t sb, uint64_t se)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    if (key_bytes != 2 && key_bytes != 4) return fail(MC_EINVAL, "key_bytes must be 2 or 4");
+    int rc = set_dev(c); if (rc) return rc;
+    rc = norm_shard(c, sb, se); if (rc) return rc;
+    // keys of the shard are one contiguous run of the arrays
+    uint64_t k0 = 0, kn = 0;
+    for (uint64_t b = 0; b < sb; b++) k0 += sz[b];
+    for (uint64_t b = sb; b < se; b++) kn += sz[b];
+    if (k0 + kn > n_keys) return fail(MC_EINVAL, "bucket sizes exceed n_keys");
+    const uint64_t nb = se - sb;
+    uint8_t *d_sz = nullptr; uint32_t *d_keys = nullptr; uint16_t *d_labels = nullptr; uint16_t *d_k16 = nullptr;
+    HIPCHK(hipMalloc(&d_sz, nb ? nb : 1));
+    HIPCHK(hipMalloc(&d_keys, (kn ? kn : 1) * 4));
+    HIPCHK(hipMalloc(&d_labels, (kn ? kn : 1) * 2));
+    HIPCHK(hipMemcpy(d_sz, sz + sb, nb, hipMemcpyHostToDevice));
+    if (kn) {
+        if (key_bytes == 4) {
+            HIPCHK(hipMemcpy(d_keys, (const uint32_t *)keys + k0, kn * 4, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(hipMalloc(&d_k16, kn * 2));
+            HIPCHK(hipMemcpy(d_k16, (const uint16_t *)keys + k0, kn * 2, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(mc::widen_keys_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->streams[0], d_k16, kn, d_keys);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->streams[0]));
+            (void)hipFree(d_k16);
+        }
+        HIPCHK(hipMemcpy(d_labels, labels + k0, kn * 2, hipMemcpyHostToDevice));
+    }
+    rc = relayout(c, d_sz, d_keys, d_labels, kn, sb, se);
+    (void)hipFree(d_sz); (void)hipFree(d_keys); (void)hipFree(d_labels);
+    return rc;
+}
+
+int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, uint64_t sb, uint64_t se)
+{
+    if (!c || !base) return fail(MC_EINVAL, "ctx/base is NULL");
+    if (key_bytes != 2 && key_bytes != 4) return fail(MC_EINVAL, "key_bytes must be 2 or 4");
+    int rc = set_dev(c); if (rc) return rc;
+    rc = norm_shard(c, sb, se); if (rc) return rc;
+    const std::string b(base);
+    int fs = open((b + ".sz").c_str(), O_RDONLY);
+    int fk = open((b + ".ky").c_str(), O_RDONLY);
+    int fl = open((b + ".lb").c_str(), O_RDONLY);
+    auto closeall = [&]() { if (fs >= 0) close(fs); if (fk >= 0) close(fk); if (fl >= 0) close(fl); };
+    if (fs < 0 || fk < 0 || fl < 0) { closeall(); return fail(MC_EIO, "Failed to open " + b + ".sz/.ky/.lb"); }
+
+    // bucket sizes of the whole table (the sampling counter runs over all non-empty
+    // buckets, reference CuClarkDB.cu:503-513)
+    std::vector<uint8_t> sz(c->htsize);
+    if (!pread_all(fs, sz.data(), c->htsize, 0)) { closeall(); return fail(MC_EIO, b + ".sz is shorter than htsize"); }
+    const bool all = sampling <= 1;
+    uint64_t nonzero = 0, file_k0 = 0, kept = 0;
+    std::vector<uint8_t> keep;
+    if (!all) keep.assign(c->htsize, 0);
+    for (uint64_t i = 0; i < c->htsize; i++) {
+        if (sz[i] == 0) continue;
+        nonzero++;
+        const bool kp = all || (nonzero % sampling) == 0;
+        if (!all) keep[i] = kp;
+        if (i < sb) file_k0 += sz[i];
+        else if (i < se && kp) kept += sz[i];
+    }
+    const uint64_t nb = se - sb;
+    uint8_t *d_sz = nullptr; uint32_t *d_keys = nullptr; uint16_t *d_labels = nullptr; uint16_t *d_k16 = nullptr;
+    HIPCHK(hipMalloc(&d_sz, nb ? nb : 1));
+    HIPCHK(hipMalloc(&d_keys, (kept ? kept : 1) * 4));
+    HIPCHK(hipMalloc(&d_labels, (kept ? kept : 1) * 2));
+    if (key_bytes == 2) HIPCHK(hipMalloc(&d_k16, (kept ? kept : 1) * 2));
+
+    // stream the shard's keys/labels through a staging buffer, dropping unsampled buckets
+    const uint64_t CH = 1ull << 24;   // buckets per step
+    std::vector<uint8_t> kbuf, lbuf;
+    uint64_t fpos = file_k0, dpos = 0;
+    for (uint64_t b0 = sb; b0 < se; b0 += CH) {
+        const uint64_t b1 = std::min(se, b0 + CH);
+        uint64_t nfile = 0;
+        for (uint64_t i = b0; i < b1; i++) nfile += sz[i];
+        kbuf.resize(nfile * (size_t)key_bytes); lbuf.resize(nfile * 2);
+        if (nfile && (!pread_all(fk, kbuf.data(), kbuf.size(), fpos * (uint64_t)key_bytes) ||
+                      !pread_all(fl, lbuf.data(), lbuf.size(), fpos * 2))) {
+            closeall(); return fail(MC_EIO, b + ".ky/.lb shorter than the bucket sizes say");
+        }
+        uint64_t nkeep = nfile;
+        if (!all) {
+            uint64_t r = 0, w = 0;
+            for (uint64_t i = b0; i < b1; i++) {
+                const uint64_t n = sz[i];
+                if (n && keep[i]) {
+                    memmove(kbuf.data() + w * key_bytes, kbuf.data() + r * key_bytes, n * key_bytes);
+                    memmove(lbuf.data() + w * 2, lbuf.data() + r * 2, n * 2);
+                    w += n;
+                } else if (n) {
+                    sz[i] = 0;
+                }
+                r += n;
+            }
+            nkeep = w;
+        }
+        if (nkeep) {
+            if (key_bytes == 4) HIPCHK(hipMemcpy(d_keys + dpos, kbuf.data(), nkeep * 4, hipMemcpyHostToDevice));
+            else                HIPCHK(hipMemcpy(d_k16 + dpos, kbuf.data(), nkeep * 2, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_labels + dpos, lbuf.data(), nkeep * 2, hipMemcpyHostToDevice));
+        }
+        fpos += nfile; dpos += nkeep;
+    }
+    closeall();
+    if (dpos != kept) return fail(MC_EINVAL, "internal: kept-key count mismatch");
+    HIPCHK(hipMemcpy(d_sz, sz.data() + sb, nb, hipMemcpyHostToDevice));
+    if (key_bytes == 2) {
+        hipLaunchKernelGGL(mc::widen_keys_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->streams[0], d_k16, kept, d_keys);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->streams[0]));
+        (void)hipFree(d_k16);
+    }
+    rc = relayout(c, d_sz, d_keys, d_labels, kept, sb, se);
+    (void)hipFree(d_sz); (void)hipFree(d_keys); (void)hipFree(d_labels);
+    return rc;
+}
+
+int mc_get_db_info(mc_ctx *c, mc_db_info *out)
+{
+    if (!c || !out) return fail(MC_EINVAL, "NULL argument");
+    if (!c->db_loaded) return fail(MC_ESTATE, "no database loaded");
+    *out = c->info;
+    return MC_OK;
+}
+
+int mc_get_stats(mc_ctx *c, mc_stats *out)
+{
+    if (!c || !out) return fail(MC_EINVAL, "NULL argument");
+    int rc = set_dev(c); if (rc) return rc;
+    unsigned long long v = 0;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(&v, c->d_over, sizeof v, hipMemcpyDeviceToHost));
+    c->stats.reads_over_maxhits = v;
+    *out = c->stats;
+    return MC_OK;
+}
+
+int mc_alloc_batches(mc_ctx *c, uint32_t n_batches, uint64_t max_reads, uint64_t max_con, int want_rows)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    if (n_batches < 1 || max_reads < 1) return fail(MC_EINVAL, "n_batches and max_reads must be >= 1");
+    if (max_con > 0xFFFFFFFFull) return fail(MC_EINVAL, "max_containers exceeds the 32-bit offsets of the batch format");
+    int rc = set_dev(c); if (rc) return rc;
+    mc_free_batches(c);
+    if (max_con < 8) max_con = 8;
+    max_con = (max_con + 7) & ~7ull;
+    c->max_reads = max_reads; c->max_con = max_con; c->want_rows = want_rows != 0;
+    const size_t row_len = 2 * (size_t)c->maxhits + 2;
+    c->batches.resize(n_batches);
+    for (auto &b : c->batches) {
+        hipError_t e = hipHostMalloc((void **)&b.h_ptr, (max_reads + 1) * 4, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_con, max_con * 2, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_final, max_reads * MC_FINAL_ROW * 2, hipHostMallocDefault);
+        if (e == hipSuccess && c->want_rows) e = hipHostMalloc((void **)&b.h_rows, max_reads * row_len * 2, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            mc_free_batches(c);
+            return fail(MC_ENOMEM, std::string("pinned batch buffers: ") + hipGetErrorString(e) +
+                                       " -- use more, smaller batches (-b)");
+        }
+    }
+    for (auto &s : c->slots) {
+        hipError_t e = hipMalloc(&s.d_ptr, (max_reads + 1) * 4);
+        if (e == hipSuccess) e = hipMalloc(&s.d_con, max_con * 2);
+        if (e == hipSuccess) e = hipMalloc(&s.d_final, max_reads * MC_FINAL_ROW * 2);
+        if (e == hipSuccess && c->want_rows) e = hipMalloc(&s.d_rows, max_reads * row_len * 2);
+        if (e != hipSuccess) {
+            mc_free_batches(c);
+            return fail(MC_ENOMEM, std::string("device batch buffers: ") + hipGetErrorString(e) +
+                                       " -- use more, smaller batches (-b)");
+        }
+    }
+    return MC_OK;
+}
+
+int mc_batch_buffers(mc_ctx *c, uint32_t batch, uint32_t **reads_ptr, uint16_t **containers,
+                     uint16_t **final_rows, uint16_t **sparse_rows)
+{
+    if (!c || batch >= c->batches.size()) return fail(MC_EINVAL, "bad batch index");
+    Batch &b = c->batches[batch];
+    if (reads_ptr) *reads_ptr = b.h_ptr;
+    if (containers) *containers = b.h_con;
+    if (final_rows) *final_rows = b.h_final;
+    if (sparse_rows) *sparse_rows = b.h_rows;
+    return MC_OK;
+}
+
+int mc_submit(mc_ctx *c, uint32_t batch, uint64_t n_reads, uint64_t n_con, uint32_t flags)
+{
+    if (!c || batch >= c->batches.size()) return fail(MC_EINVAL, "bad batch index");
+    if (!c->db_loaded) return fail(MC_ESTATE, "mc_submit before a database was loaded");
+    if (n_reads > c->max_reads || n_con > c->max_con) return fail(MC_EINVAL, "batch larger than allocated");
+    if (!(flags & (MC_F_FINAL | MC_F_ROWS))) return fail(MC_EINVAL, "flags select no output");
+    if ((flags & MC_F_ROWS) && !c->want_rows) return fail(MC_ESTATE, "sparse rows were not allocated");
+    int rc = set_dev(c); if (rc) return rc;
+    Batch &b = c->batches[batch];
+    if (n_reads && b.h_ptr[n_reads] != n_con) return fail(MC_EINVAL, "reads_ptr[n_reads] != n_containers");
+    const int si = (int)(batch & 1u);
+    Slot &s = c->slots[si];
+    hipStream_t st = c->streams[si];
+    const size_t row_len = 2 * (size_t)c->maxhits + 2;
+    if (n_reads) {
+        HIPCHK(hipMemcpyAsync(s.d_ptr, b.h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+        if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, b.h_con, n_con * 2, hipMemcpyHostToDevice, st));
+        rc = launch_query(c, s.d_ptr, s.d_con, n_reads, n_con, flags, s.d_final, s.d_rows, st);
+        if (rc) return rc;
+        if (flags & MC_F_FINAL)
+            HIPCHK(hipMemcpyAsync(b.h_final, s.d_final, n_reads * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, st));
+        if (flags & MC_F_ROWS)
+            HIPCHK(hipMemcpyAsync(b.h_rows, s.d_rows, n_reads * row_len * 2, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipEventRecord(b.ev, st));
+    b.submitted = true;
+    return MC_OK;
+}
+
+int mc_wait(mc_ctx *c, uint32_t batch)
+{
+    if (!c || batch >= c->batches.size()) return fail(MC_EINVAL, "bad batch index");
+    Batch &b = c->batches[batch];
+    if (!b.submitted) return fail(MC_ESTATE, "batch was never submitted");
+    int rc = set_dev(c); if (rc) return rc;
+    HIPCHK(hipEventSynchronize(b.ev));
+    return MC_OK;
+}
+
+int mc_sync(mc_ctx *c)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    int rc = set_dev(c); if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    return MC_OK;
+}
+
+int mc_free_batches(mc_ctx *c)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &b : c->batches) {
+        if (b.h_ptr) (void)hipHostFree(b.h_ptr);
+        if (b.h_con) (void)hipHostFree(b.h_con);
+        if (b.h_final) (void)hipHostFree(b.h_final);
+        if (b.h_rows) (void)hipHostFree(b.h_rows);
+        if (b.ev) (void)hipEventDestroy(b.ev);
+    }
+    c->batches.clear();
+    for (auto &s : c->slots) {
+        if (s.d_ptr) (void)hipFree(s.d_ptr);
+        if (s.d_con) (void)hipFree(s.d_con);
+        if (s.d_final) (void)hipFree(s.d_final);
+        if (s.d_rows) (void)hipFree(s.d_rows);
+        s = Slot();
+    }
+    return MC_OK;
+}
+
+int mc_query_device(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads, uint64_t n_con,
+                    uint32_t flags, uint16_t *d_final, uint16_t *d_rows, void *stream)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    if (!c->db_loaded) return fail(MC_ESTATE, "mc_query_device before a database was loaded");
+    if (!(flags & (MC_F_FINAL | MC_F_ROWS))) return fail(MC_EINVAL, "flags select no output");
+    if ((flags & MC_F_FINAL) && !d_final) return fail(MC_EINVAL, "MC_F_FINAL without d_final_rows");
+    if ((flags & MC_F_ROWS) && !d_rows) return fail(MC_EINVAL, "MC_F_ROWS without d_sparse_rows");
+    int rc = set_dev(c); if (rc) return rc;
+    return launch_query(c, d_ptr, d_con, n_reads, n_con, flags, d_final, d_rows,
+                        stream ? (hipStream_t)stream : c->streams[0]);
+}
+
+int mc_merge_rows_device(mc_ctx *c, const uint16_t *d_a, const uint16_t *d_b, uint64_t n_reads,
+                         uint16_t *d_out, void *stream)
+{
+    if (!c || !d_a || !d_b || !d_out) return fail(MC_EINVAL, "NULL argument");
+    int rc = set_dev(c); if (rc) return rc;
+    if (n_reads == 0) return MC_OK;
+    const uint32_t row_len = 2 * c->maxhits + 2;
+    const uint32_t g = (uint32_t)((n_reads + 255) / 256);
+    hipLaunchKernelGGL(mc::merge_rows_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : c->streams[0],
+                       d_a, d_b, row_len, n_reads, d_out);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+int mc_result_rows_device(mc_ctx *c, const uint16_t *d_rows, uint64_t n_reads, uint16_t *d_final, void *stream)
+{
+    if (!c || !d_rows || !d_final) return fail(MC_EINVAL, "NULL argument");
+    int rc = set_dev(c); if (rc) return rc;
+    if (n_reads == 0) return MC_OK;
+    const uint32_t row_len = 2 * c->maxhits + 2;
+    const uint32_t g = (uint32_t)((n_reads + 255) / 256);
+    hipLaunchKernelGGL(mc::result_rows_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : c->streams[0],
+                       d_rows, row_len, n_reads, d_final);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+} // extern "C"

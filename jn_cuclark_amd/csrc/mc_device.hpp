@@ -1,0 +1,543 @@
+// mc_device.hpp -- CDNA4 (gfx950, wave64) kernels of the classifier core.
+//
+// Replaces the three CUDA kernels of the reference (src/CuClarkDB.cu:999-1411):
+//   queryKernel + queryElement  -> mc::query_kernel<LINE>  (fused with resultKernel
+//                                  when only the final rows are wanted)
+//   mergeKernel                 -> mc::merge_rows_kernel
+//   resultKernel                -> mc::result_rows_kernel
+// plus the load-time re-layout kernels that turn the on-disk bucket arrays
+// (.sz/.ky/.lb, reference src/hashTable_hh.hh:473-546) into "bucket lines".
+//
+// Design:
+//   * integer hash + random gather, HBM-transaction bound; no MFMA.
+//   * one 64-lane wavefront walks one read: lane i owns k-mer i (and i+64, both probes
+//     in flight together); waves are independent (no workgroup barrier anywhere).
+//   * a wave stages the packed containers of a GROUP of reads into its private LDS
+//     slice with 16-byte coalesced loads; lanes then cut their k-mers out of LDS.
+//   * the table is re-laid out so that ONE probe touches ONE aligned line
+//     (keys + labels + size of the bucket together), instead of the reference's three
+//     dependent reads (bucketPointers[r], [r+1] -> keys[] -> labels[]).
+//   * per-target hit counts live in registers: lane j of the wave holds the j-th
+//     distinct target seen for the read (id, count); hits are folded in with
+//     ballot/readlane, never through a T-sized shared array (reference :1017-1026).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mc {
+
+// ---------------------------------------------------------------------------
+// division by the (run-time) table size: q = c / HTSIZE, r = c % HTSIZE
+// (reference CuClarkDB.cu:1208-1209 divides by a compile-time constant)
+// ---------------------------------------------------------------------------
+struct DivU64 {
+    uint64_t d;
+    uint64_t magic;   // 0 => d is a power of two
+    uint32_t shift;
+    uint32_t add;
+};
+
+__device__ __forceinline__ uint64_t div_u64(uint64_t n, const DivU64 &dv)
+{
+    if (dv.magic == 0) return n >> dv.shift;
+    uint64_t q = __umul64hi(dv.magic, n);
+    if (dv.add) {
+        uint64_t t = ((n - q) >> 1) + q;
+        return t >> dv.shift;
+    }
+    return q >> dv.shift;
+}
+
+// ---------------------------------------------------------------------------
+// bucket lines
+//   LINE bytes per bucket, CAP = (LINE-4)/6 k-mers:
+//     dword [0, CAP)            keys (quotients, ascending; unused = 0xFFFFFFFF)
+//     dword [CAP, CAP+CAP/2)    labels, two u16 per dword
+//     dword LINE/4-1            header: low byte = number of keys, or 0xFF when the
+//                               bucket did not fit: then dword0|dword1<<32 = offset
+//                               into the overflow arrays and dword2 = its size.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
+static constexpr uint32_t HDR_OVERFLOW = 0xFFu;
+
+template <int LINE> struct LineCfg {
+    static constexpr int DW   = LINE / 4;
+    static constexpr int CAP  = (LINE - 4) / 6;
+    static constexpr int LAB0 = CAP;       // first label dword
+    static constexpr int HDR  = DW - 1;
+};
+
+struct QueryArgs {
+    const uint32_t *reads_ptr;      // n_reads+1 container offsets (ref :1034-1035)
+    const uint16_t *containers;     // [len][containers...] per part (ref :1044-1046)
+    uint64_t n_reads;
+    uint64_t n_containers;
+    const uint8_t  *lines;          // bucket lines of this shard
+    const uint32_t *ovf_keys;
+    const uint16_t *ovf_labels;
+    uint64_t shard_begin;           // ref dbPartStart / dbPartEnd (:1212-1214)
+    uint64_t shard_end;
+    DivU64   div;
+    uint32_t k;
+    uint32_t maxhits;
+    uint32_t flags;                 // MC_F_FINAL | MC_F_ROWS
+    uint32_t stage_ok;              // containers pointer is 16-byte aligned
+    uint16_t *final_rows;           // 5 u16 per read
+    uint16_t *sparse_rows;          // 2*maxhits+2 u16 per read
+    unsigned long long *over_maxhits;
+};
+
+static constexpr int WAVES_PER_BLOCK = 4;
+static constexpr int BLOCK_THREADS   = 64 * WAVES_PER_BLOCK;
+static constexpr int GROUP_READS     = 16;     // reads staged per wave at a time
+static constexpr int STAGE_CON       = 1024;   // u16 containers per wave LDS slice
+
+// reverse complement: complement every 2-bit code, reverse the order of the codes,
+// keep the low 2k bits.  Same function as reference CuClarkDB.cu:1196-1203, written
+// with v_bfrev_b32 instead of five swap rounds.
+__device__ __forceinline__ uint64_t revcomp(uint64_t x, uint32_t k)
+{
+    uint64_t r = __brevll(~x);
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    return r >> (64u - 2u * k);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+// One probe's line, in registers.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int LINE> struct LineRegs { u32x4 v[LINE / 16]; };
+
+template <int LINE>
+__device__ __forceinline__ void line_load(LineRegs<LINE> &L, const uint8_t *lines, uint64_t idx)
+{
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(lines + idx * (uint64_t)LINE);
+#pragma unroll
+    for (int i = 0; i < LINE / 16; i++) L.v[i] = __builtin_nontemporal_load(p + i);
+}
+
+template <int LINE>
+__device__ __forceinline__ uint32_t line_dw(const LineRegs<LINE> &L, int i)
+{
+    return L.v[i >> 2][i & 3];
+}
+
+// Lookup of quotient q in a loaded line.  Equivalent to the scan of reference
+// CuClarkDB.cu:1226-1250 for ascending distinct keys: the lowest matching index wins.
+template <int LINE>
+__device__ __forceinline__ bool line_find(const LineRegs<LINE> &L, uint32_t q,
+                                          const uint32_t *ovf_keys, const uint16_t *ovf_labels,
+                                          uint32_t &label)
+{
+    using C = LineCfg<LINE>;
+    const uint32_t hdr = line_dw<LINE>(L, C::HDR) & 0xFFu;
+    bool hit = false;
+    if (hdr != HDR_OVERFLOW) {
+#pragma unroll
+        for (int i = C::CAP - 1; i >= 0; i--) {
+            const uint32_t key = line_dw<LINE>(L, i);
+            const uint32_t lw  = line_dw<LINE>(L, C::LAB0 + (i >> 1));
+            const uint32_t lab = (i & 1) ? (lw >> 16) : (lw & 0xFFFFu);
+            if (key == q) { hit = true; label = lab; }
+        }
+    } else {
+        const uint64_t off = (uint64_t)line_dw<LINE>(L, 0) | ((uint64_t)line_dw<LINE>(L, 1) << 32);
+        const uint32_t n   = line_dw<LINE>(L, 2);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t key = ovf_keys[off + i];
+            if (key == q) { hit = true; label = ovf_labels[off + i]; break; }
+            if (key > q) break;
+        }
+    }
+    return hit;
+}
+
+// ---------------------------------------------------------------------------
+// the query kernel
+// ---------------------------------------------------------------------------
+template <int LINE>
+__global__ __launch_bounds__(BLOCK_THREADS)
+void query_kernel(const QueryArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_con[WAVES_PER_BLOCK][STAGE_CON + 16];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint16_t *slice = s_con[wave];
+
+    const uint32_t k = a.k;
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
+    const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
+    const uint64_t gstride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t row_len = 2u * a.maxhits + 2u;
+
+    for (uint64_t g = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; g < n_groups; g += gstride) {
+        const uint64_t r0 = g * GROUP_READS;
+        const uint32_t nr = (uint32_t)((a.n_reads - r0) < GROUP_READS ? (a.n_reads - r0) : GROUP_READS);
+
+        // container offsets of the group's reads: lane i holds reads_ptr[r0 + i]
+        uint32_t ptr_v = 0;
+        if (lane <= nr) ptr_v = a.reads_ptr[r0 + lane];
+        const uint32_t c0 = __builtin_amdgcn_readlane(ptr_v, 0);
+        const uint32_t c1 = __shfl(ptr_v, nr, 64);
+        const uint32_t c0a = c0 & ~7u;
+
+        // stage [c0a, c1) into this wave's LDS slice (16-byte loads, coalesced)
+        const bool staged = a.stage_ok && (c1 - c0a) <= (uint32_t)STAGE_CON;
+        if (staged) {
+            for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
+                const uint64_t gi = (uint64_t)c0a + j;
+                if (gi + 8u <= a.n_containers) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(a.containers + gi);
+                    *reinterpret_cast<uint4 *>(slice + j) = v;
+                } else {
+                    for (uint32_t t = 0; t < 8u; t++)
+                        slice[j + t] = (gi + t < a.n_containers) ? a.containers[gi + t] : (uint16_t)0;
+                }
+            }
+            // LDS is in order per wave; only the compiler must not reorder
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // container i of the batch (absolute index); every access is clamped so that
+        // malformed input can only produce wrong counts, never an out-of-range access
+        auto con = [&](uint32_t i) -> uint32_t {
+            if (staged) {
+                const uint32_t li = i - c0a;
+                return slice[li < (uint32_t)(STAGE_CON + 15) ? li : (uint32_t)(STAGE_CON + 15)];
+            }
+            const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
+            return a.containers[ii];
+        };
+
+        for (uint32_t ri = 0; ri < nr; ri++) {
+            const uint32_t beg = (uint32_t)__shfl((int)ptr_v, (int)ri, 64);
+            uint32_t end = (uint32_t)__shfl((int)ptr_v, (int)ri + 1, 64);
+            if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
+
+            // accumulator: lane j = j-th distinct target of this read
+            uint32_t acc_t = 0xFFFFFFFFu, acc_c = 0;
+            uint32_t n_acc = 0;          // wave-uniform
+
+            uint32_t pp = beg;
+            while (pp < end) {                                  // parts (ref :1042-1117)
+                const uint32_t plen = con(pp);
+                const uint32_t first = pp + 1;
+                pp = first + (plen ? (plen - 1u) / 8u + 1u : 0u);
+                if (plen < k) continue;
+                const uint32_t nk = plen - k + 1u;
+
+                for (uint32_t base = 0; base < nk; base += 128u) {
+                    bool     act[2];
+                    uint32_t q32[2];
+                    uint64_t lidx[2];
+                    LineRegs<LINE> L[2];
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        const uint32_t p = base + 64u * s + lane;
+                        act[s] = p < nk;
+                        q32[s] = 0; lidx[s] = 0;
+                        if (act[s]) {
+                            // 80-bit window = containers j0..j0+4, first base in the top bits
+                            const uint32_t j0 = first + (p >> 3);
+                            const uint64_t hi = ((uint64_t)con(j0) << 48) | ((uint64_t)con(j0 + 1) << 32)
+                                              | ((uint64_t)con(j0 + 2) << 16) | (uint64_t)con(j0 + 3);
+                            const uint32_t lo = con(j0 + 4);
+                            const uint32_t sh = 80u - 2u * (p & 7u) - 2u * k;   // >= 2
+                            uint64_t x = sh >= 16u ? (hi >> (sh - 16u))
+                                                   : ((hi << (16u - sh)) | (uint64_t)(lo >> sh));
+                            x &= kmask;
+                            const uint64_t rc = revcomp(x, k);
+                            const uint64_t c  = x < rc ? x : rc;               // canonical (ref :1206)
+                            const uint64_t q  = div_u64(c, a.div);
+                            const uint64_t r  = c - q * a.div.d;
+                            act[s] = (r >= a.shard_begin) && (r < a.shard_end);   // ref :1212-1214
+                            q32[s] = (uint32_t)q;
+                            lidx[s] = r - a.shard_begin;
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+                        if (act[s]) line_load<LINE>(L[s], a.lines, lidx[s]);
+
+                    bool     hit[2];
+                    uint32_t lab[2];
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        hit[s] = false; lab[s] = 0;
+                        if (act[s]) hit[s] = line_find<LINE>(L[s], q32[s], a.ovf_keys, a.ovf_labels, lab[s]);
+                    }
+
+                    // fold the hits of this step into the accumulator, one distinct
+                    // target per iteration (wave-uniform control flow)
+                    uint64_t m0 = __ballot(hit[0]);
+                    uint64_t m1 = __ballot(hit[1]);
+                    while (m0 | m1) {
+                        uint32_t t;
+                        if (m0) t = (uint32_t)__shfl((int)lab[0], __ffsll((unsigned long long)m0) - 1, 64);
+                        else    t = (uint32_t)__shfl((int)lab[1], __ffsll((unsigned long long)m1) - 1, 64);
+                        const uint64_t s0 = __ballot(hit[0] && lab[0] == t);
+                        const uint64_t s1 = __ballot(hit[1] && lab[1] == t);
+                        const uint32_t cnt = (uint32_t)(__popcll(s0) + __popcll(s1));
+                        m0 &= ~s0; m1 &= ~s1;
+                        if (lab[0] == t) hit[0] = false;
+                        if (lab[1] == t) hit[1] = false;
+
+                        const uint64_t ex = __ballot(acc_t == t);
+                        if (ex) {
+                            if (acc_t == t) acc_c += cnt;
+                        } else if (n_acc < 64u) {
+                            if (lane == n_acc) { acc_t = t; acc_c = cnt; }
+                            n_acc++;
+                        } else {
+                            // 64 distinct targets already: keep the 64 smallest ids
+                            const uint32_t mx = wave_max_u32(acc_t);
+                            if (t < mx) {
+                                const uint64_t who = __ballot(acc_t == mx);
+                                if (lane == (uint32_t)(__ffsll((unsigned long long)who) - 1)) { acc_t = t; acc_c = cnt; }
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- finalisation for this read ---------------------------------
+            const uint64_t rd = r0 + ri;
+            bool valid = lane < n_acc;
+            uint32_t rank = 0;
+            const bool need_rank = (a.flags & 2u) || (n_acc > a.maxhits);
+            if (need_rank) {
+                for (uint32_t j = 0; j < n_acc; j++) {
+                    const uint32_t tj = (uint32_t)__shfl((int)acc_t, (int)j, 64);
+                    rank += (tj < acc_t) ? 1u : 0u;
+                }
+                if (n_acc > a.maxhits) {
+                    valid = valid && rank < a.maxhits;
+                    if (lane == 0) atomicAdd(a.over_maxhits, 1ull);
+                }
+            }
+            const uint32_t n_keep = n_acc > a.maxhits ? a.maxhits : n_acc;
+
+            if (a.flags & 2u) {                                   // sparse row (ref :1120-1182)
+                // every element of the row is written exactly once
+                uint16_t *row = a.sparse_rows + rd * row_len;
+                if (lane == 0) row[0] = (uint16_t)n_keep;
+                if (valid) {
+                    row[1 + 2 * rank] = (uint16_t)acc_t;
+                    row[2 + 2 * rank] = (uint16_t)acc_c;
+                }
+                for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
+            }
+            if (a.flags & 1u) {                                   // fused top-2 (ref :1361-1411)
+                // ascending-id scan with strict '>' == max count, ties to the smaller id
+                const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
+                const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
+                const uint32_t k1  = wave_max_u32(key);
+                const uint32_t k2  = wave_max_u32(key == k1 ? 0u : key);
+                const uint32_t sum = wave_sum_u32(valid ? acc_c : 0u);
+                uint32_t out = 0;
+                switch (lane) {
+                case 0: out = sum & 0xFFFFu; break;
+                case 1: out = k1 ? (0xFFFFu - (k1 & 0xFFFFu)) + 1u : 0u; break;
+                case 2: out = k1 >> 16; break;
+                case 3: out = k2 ? (0xFFFFu - (k2 & 0xFFFFu)) + 1u : 0u; break;
+                case 4: out = k2 >> 16; break;
+                default: break;
+                }
+                if (lane < 5u) a.final_rows[rd * 5u + lane] = (uint16_t)out;
+            }
+        }
+        // the slice is rewritten by the next group: keep the compiler from hoisting
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// merge / result (one thread per read), for the sharded path
+// ---------------------------------------------------------------------------
+// ref CuClarkDB.cu:1261-1355; keeps the maxhits smallest ids when the union is larger.
+__global__ void merge_rows_kernel(const uint16_t *A, const uint16_t *B, uint32_t row_len,
+                                  uint64_t n_reads, uint16_t *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint16_t *ra = A + r * row_len, *rb = B + r * row_len;
+    uint16_t *ro = out + r * row_len;
+    const uint32_t maxhits = (row_len - 2u) / 2u;
+    const uint32_t na = ra[0], nb = rb[0];
+    uint16_t tmp[2 * 63 + 2];
+    uint32_t ia = 0, ib = 0, n = 0;
+    while ((ia < na || ib < nb) && n < maxhits) {
+        uint16_t t, h;
+        const uint16_t ta = ia < na ? ra[1 + 2 * ia] : (uint16_t)0xFFFF;
+        const uint16_t tb = ib < nb ? rb[1 + 2 * ib] : (uint16_t)0xFFFF;
+        if (ib >= nb || (ia < na && ta < tb))      { t = ta; h = ra[2 + 2 * ia]; ia++; }
+        else if (ia >= na || tb < ta)              { t = tb; h = rb[2 + 2 * ib]; ib++; }
+        else { t = ta; h = (uint16_t)(ra[2 + 2 * ia] + rb[2 + 2 * ib]); ia++; ib++; }
+        tmp[1 + 2 * n] = t; tmp[2 + 2 * n] = h; n++;
+    }
+    tmp[0] = (uint16_t)n;
+    for (uint32_t i = 0; i < row_len; i++) ro[i] = i < 1u + 2u * n ? tmp[i] : (uint16_t)0;
+}
+
+// ref CuClarkDB.cu:1361-1411
+__global__ void result_rows_kernel(const uint16_t *rows, uint32_t row_len, uint64_t n_reads,
+                                   uint16_t *out5)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint16_t *row = rows + r * row_len;
+    uint16_t best = 0, s_best = 0, ibest = 0, isbest = 0, sum = 0;
+    const uint32_t count = row[0];
+    for (uint32_t i = 0; i < count; i++) {
+        const uint16_t sc = row[2 * i + 2];
+        if (sc > best) { s_best = best; isbest = ibest; best = sc; ibest = (uint16_t)(row[2 * i + 1] + 1); }
+        else if (sc > s_best) { s_best = sc; isbest = (uint16_t)(row[2 * i + 1] + 1); }
+        sum = (uint16_t)(sum + sc);
+    }
+    uint16_t *o = out5 + r * 5;
+    o[0] = sum; o[1] = ibest; o[2] = best; o[3] = isbest; o[4] = s_best;
+}
+
+// ---------------------------------------------------------------------------
+// load-time re-layout: (sizes u8, keys u32, labels u16) -> bucket lines
+// ---------------------------------------------------------------------------
+static constexpr int RL_THREADS = 256;
+static constexpr int RL_PER_THREAD = 4;
+static constexpr int RL_BUCKETS = RL_THREADS * RL_PER_THREAD;   // buckets per workgroup
+
+// histogram of bucket sizes (256 bins) -- picks the line size
+__global__ void size_hist_kernel(const uint8_t *sz, uint64_t n_buckets, unsigned long long *hist)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride)
+        atomicAdd(&h[sz[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t w = 0; w < RL_THREADS / 64; w++) { if (w < wave) pre += s_wave[w]; tot += s_wave[w]; }
+    __syncthreads();
+    total = tot;
+    return pre + inc - v;
+}
+
+// per workgroup of RL_BUCKETS buckets: number of keys, and number of keys living in
+// buckets larger than `cap`
+__global__ __launch_bounds__(RL_THREADS)
+void block_sums_kernel(const uint8_t *sz, uint64_t n_buckets, uint32_t cap,
+                       uint32_t *blk_keys, uint32_t *blk_ovf)
+{
+    __shared__ uint32_t s_a[RL_THREADS / 64], s_b[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    uint32_t keys = 0, ovf = 0;
+    for (int i = 0; i < RL_PER_THREAD; i++) {
+        const uint32_t c = (b0 + i < n_buckets) ? sz[b0 + i] : 0u;
+        keys += c;
+        if (c > cap) ovf += c;
+    }
+    uint32_t tk, to;
+    block_exclusive_scan(keys, s_a, tk);
+    block_exclusive_scan(ovf, s_b, to);
+    if (threadIdx.x == 0) { blk_keys[blockIdx.x] = tk; blk_ovf[blockIdx.x] = to; }
+}
+
+template <int LINE>
+__global__ __launch_bounds__(RL_THREADS)
+void fill_lines_kernel(const uint8_t *sz, const uint32_t *keys, const uint16_t *labels,
+                       uint64_t n_buckets, const uint64_t *blk_key_off, const uint64_t *blk_ovf_off,
+                       uint8_t *lines, uint32_t *ovf_keys, uint16_t *ovf_labels)
+{
+    using C = LineCfg<LINE>;
+    __shared__ uint32_t s_a[RL_THREADS / 64], s_b[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    uint32_t cnt[RL_PER_THREAD];
+    uint32_t ksum = 0, osum = 0;
+#pragma unroll
+    for (int i = 0; i < RL_PER_THREAD; i++) {
+        cnt[i] = (b0 + i < n_buckets) ? sz[b0 + i] : 0u;
+        ksum += cnt[i];
+        if (cnt[i] > (uint32_t)C::CAP) osum += cnt[i];
+    }
+    uint32_t tk, to;
+    uint64_t koff = blk_key_off[blockIdx.x] + block_exclusive_scan(ksum, s_a, tk);
+    uint64_t ooff = blk_ovf_off[blockIdx.x] + block_exclusive_scan(osum, s_b, to);
+
+#pragma unroll
+    for (int i = 0; i < RL_PER_THREAD; i++) {
+        const uint64_t b = b0 + i;
+        if (b >= n_buckets) break;
+        const uint32_t c = cnt[i];
+        uint32_t dw[C::DW];
+#pragma unroll
+        for (int j = 0; j < C::DW; j++) dw[j] = 0;
+#pragma unroll
+        for (int j = 0; j < C::CAP; j++) dw[j] = KEY_SENTINEL;
+        if (c <= (uint32_t)C::CAP) {
+#pragma unroll
+            for (int j = 0; j < C::CAP; j++) {
+                if ((uint32_t)j < c) {
+                    dw[j] = keys[koff + j];
+                    const uint32_t lab = labels[koff + j];
+                    dw[C::LAB0 + (j >> 1)] |= (j & 1) ? (lab << 16) : lab;
+                }
+            }
+            dw[C::HDR] = c;
+        } else {
+            for (uint32_t j = 0; j < c; j++) {
+                ovf_keys[ooff + j] = keys[koff + j];
+                ovf_labels[ooff + j] = labels[koff + j];
+            }
+            dw[0] = (uint32_t)ooff; dw[1] = (uint32_t)(ooff >> 32); dw[2] = c;
+            dw[C::HDR] = HDR_OVERFLOW;
+            ooff += c;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(lines + b * (uint64_t)LINE);
+#pragma unroll
+        for (int j = 0; j < LINE / 16; j++)
+            dst[j] = make_uint4(dw[4 * j], dw[4 * j + 1], dw[4 * j + 2], dw[4 * j + 3]);
+        koff += c;
+    }
+}
+
+// widen 16-bit keys (k <= 23 full / k <= 20 light databases, reference main.cc:255-263)
+__global__ void widen_keys_kernel(const uint16_t *in, uint64_t n, uint32_t *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
+} // namespace mc

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE's own CPU code.
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py            # light table (HTSIZE 57777779, k=27)
+    python tests/golden/make_golden.py --full     # + full table (HTSIZE 1610612741, k=31, ~30 GB RAM)
+
+What the reference computes here (oracle/ref_ht_driver.cc is only a harness around it):
+  * kmer_vectors.npz   string -> value / reverse complement
+                       (vectorToIndex + getReverseComplement, src/kmersConversion.cc:39-87)
+  * db_<variant>.npz   occurrences -> discriminative database files
+                       (EHashtable::addElement -> SortAllHashTable -> RemoveCommon -> Write,
+                        src/HashTableStorage_hh.hh:421-461, :229-280, src/hashTable_hh.hh:473-546)
+                       and lookups (EHashtable::Read + queryElement(uint64) = hTable::find,
+                        src/hashTable_hh.hh:358-396) -- the function the GPU lookup mirrors
+                        (src/CuClarkDB.cu:1185-1254).
+The fixtures are data (inputs + the reference's outputs); no reference source is stored.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from jn_cuclark_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, check=True, capture_output=True, text=True, **kw).stdout
+
+
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def kmer_vectors(tmp):
+    rows = {}
+    for k, exe in ((27, "ref_ht_light"), (31, "ref_ht_full"), (32, "ref_ht_full"), (20, "ref_ht_light")):
+        codes = synth.random_codes(1000 + k, 64 * k).reshape(64, k)
+        strs = [synth.codes_to_ascii(c).decode() for c in codes]
+        # a few hand-picked ones: homopolymers, palindromes, lower case
+        strs += ["A" * k, "C" * k, "G" * k, "T" * k, ("AC" * k)[:k], ("acgt" * k)[:k], ("TTAA" * k)[:k]]
+        p = os.path.join(tmp, "km%d.txt" % k)
+        open(p, "w").write("\n".join(strs) + "\n")
+        out = run([os.path.join(REF, exe), "kmer", str(k), p])
+        fw, rv = [], []
+        for line in out.strip().split("\n"):
+            s, a, b = line.split("\t")
+            fw.append(int(a)); rv.append(int(b))
+        rows["k%d_str" % k] = np.array(strs)
+        rows["k%d_fwd" % k] = np.array(fw, dtype=np.uint64)
+        rows["k%d_rc" % k] = np.array(rv, dtype=np.uint64)
+    np.savez_compressed(os.path.join(OUT, "kmer_vectors.npz"), **rows)
+    print("kmer_vectors.npz written")
+
+
+def db_fixture(tmp, variant, exe, k, htsize, seed):
+    # three toy genomes; genome 1 shares a block with genome 0 (non-discriminative),
+    # genome 2 contains an internal repeat (same k-mers twice in ONE target: kept)
+    genomes = synth.toy_genomes(3, 3000, seed, shared=400)
+    genomes[2] = genomes[2].copy()
+    genomes[2][2000:2200] = genomes[2][100:300]
+    # plus the reverse complement of a stretch of genome 0 placed in genome 1
+    rc_block = (3 - genomes[0][1000:1200])[::-1]
+    genomes[1] = genomes[1].copy()
+    genomes[1][2500:2700] = rc_block
+    km = np.concatenate([synth.kmers_of(g, k) for g in genomes])
+    tg = np.concatenate([np.full(g.size - k + 1, i, dtype=np.uint16) for i, g in enumerate(genomes)])
+    tsv = os.path.join(tmp, "occ_%s.tsv" % variant)
+    with open(tsv, "w") as f:
+        for x, t in zip(km.tolist(), tg.tolist()):
+            f.write("%d\tt%d\n" % (x, t))
+    base = os.path.join(tmp, "db_%s" % variant)
+    out = run([os.path.join(REF, exe), "build", str(k), "0", tsv, base])
+    stored = int([ln for ln in out.split("\n") if ln.startswith("stored")][0].split("\t")[1])
+    sz = np.fromfile(base + ".sz", dtype=np.uint8)
+    ky = np.fromfile(base + ".ky", dtype=np.uint32)
+    lb = np.fromfile(base + ".lb", dtype=np.uint16)
+    assert sz.size == htsize and ky.size == stored and lb.size == stored
+    nz = np.flatnonzero(sz).astype(np.uint32)
+
+    # lookups: every genome k-mer, its reverse complement, neighbours and random values
+    q = np.concatenate([km, synth.revcomp(km, k), km ^ np.uint64(1),
+                        synth.rand_u64(seed + 77, 3000) & np.uint64((1 << (2 * k)) - 1)])
+    qp = os.path.join(tmp, "q_%s.txt" % variant)
+    np.savetxt(qp, q, fmt="%d")
+    res = run([os.path.join(REF, exe), "query", str(k), base, qp])
+    found, label = [], []
+    for line in res.strip().split("\n"):
+        _, a, b = line.split("\t")
+        found.append(int(a)); label.append(int(b))
+    np.savez_compressed(
+        os.path.join(OUT, "db_%s.npz" % variant),
+        k=np.int64(k), htsize=np.int64(htsize),
+        occ_kmers=km, occ_targets=tg,
+        nonzero_buckets=nz, nonzero_sizes=sz[nz], keys=ky, labels=lb,
+        sha256=np.array([sha(base + ".sz"), sha(base + ".ky"), sha(base + ".lb")]),
+        query_kmers=q, query_found=np.array(found, dtype=np.uint8), query_label=np.array(label, dtype=np.uint16))
+    for ext in (".sz", ".ky", ".lb"):
+        os.remove(base + ext)
+    print("db_%s.npz written: %d stored k-mers, %d lookups, %d found" % (variant, stored, q.size, sum(found)))
+
+
+def main():
+    full = "--full" in sys.argv
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        kmer_vectors(tmp)
+        db_fixture(tmp, "light_k27", "ref_ht_light", 27, 57777779, 11)
+        if full:
+            db_fixture(tmp, "full_k31", "ref_ht_full", 31, 1610612741, 12)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Shared builders for the parity tests (small synthetic databases + read batches)."""
+import numpy as np
+
+from jn_cuclark_amd import synth
+
+
+def small_db(seed=5, k=21, htsize=1000003, n_targets=6, glen=4000, shared=300):
+    genomes = synth.toy_genomes(n_targets, glen, seed, shared=shared)
+    sz, ky, lb = synth.genome_db(genomes, k, htsize)
+    return genomes, sz, ky, lb
+
+
+def mixed_fasta(genomes, k, seed=9, n=300, length=150):
+    """FASTA text exercising the packer: sampled reads with substitutions, random
+    reads, reads with N (two parts), lower case, U, reads shorter than k, a part
+    shorter than k between two long ones, multi-line records, an all-N read."""
+    codes, _ = synth.sample_reads(genomes, n, length, seed)
+    names, seqs = [], []
+    rnd = synth.rand_u64(seed, n, stream=9)
+    for i in range(n):
+        s = bytearray(synth.codes_to_ascii(codes[i]))
+        kind = int(rnd[i] % np.uint64(12))
+        if kind == 0:                       # one N in the middle -> two parts
+            s[int(rnd[i] >> np.uint64(8)) % length] = ord("N")
+        elif kind == 1:                     # lower case
+            s = bytearray(bytes(s).lower())
+        elif kind == 2:                     # RNA
+            s = bytearray(bytes(s).replace(b"T", b"U"))
+        elif kind == 3:                     # shorter than k
+            s = s[: k - 1 - (i % 5)]
+        elif kind == 4:                     # short part between two long parts
+            s[40] = ord("N"); s[40 + 1 + (i % (k - 1))] = ord("N")
+        elif kind == 5:                     # short part at the end
+            s[length - 1 - (i % (k - 1))] = ord("N")
+        elif kind == 6:                     # short part at the start
+            s[i % (k - 1)] = ord("N")
+        elif kind == 7:                     # uniform random read (no hits expected)
+            s = bytearray(synth.codes_to_ascii(synth.random_codes(seed * 1000 + i, length)))
+        elif kind == 8 and i % 3 == 0:      # all N
+            s = bytearray(b"N" * length)
+        elif kind == 9:                     # other IUPAC symbols end parts too
+            s[75] = ord("R"); s[76] = ord("-")
+        names.append(("read%d_%d some description" % (i, kind)).encode())
+        seqs.append(bytes(s))
+    return names, seqs
+
+
+def pack_with_oracle(oracle, text, k):
+    ns, ne, sp, ep, ln = oracle.index_reads(text)
+    rp, con = oracle.pack_reads(text, sp, ep, ln, k)
+    return (ns, ne, sp, ep, ln), rp, con

@@ -1,0 +1,257 @@
+"""GPU suite: the HIP path (through the C ABI of libmcclark.so) against the oracle on
+the same seeded inputs.  Bit-exact: everything on this path is integer."""
+import os
+
+import numpy as np
+import pytest
+
+from jn_cuclark_amd import synth
+from helpers import small_db, mixed_fasta, pack_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+K, HT = 21, 1000003
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the product has no CPU fallback")
+    from jn_cuclark_amd import CuClarkDB
+    return CuClarkDB
+
+
+def _open(gpu, sz, ky, lb, k=K, ht=HT, maxhits=15, ntargets=16, shard=(0, 0)):
+    db = gpu(k=k, numBatches=2, numTargets=ntargets, device=0, htsize=ht, maxhits=maxhits)
+    db.read_arrays(sz, ky, lb, shard=shard)
+    return db
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+def test_mixed_reads_bit_exact(gpu, oracle, fmt):
+    """ragged input: N-split reads, short reads, short parts, lower case, U, all-N"""
+    genomes, sz, ky, lb = small_db()
+    names, seqs = mixed_fasta(genomes, K, n=2000)
+    text = synth.fastq_text(names, seqs) if fmt == "fastq" else synth.fasta_text(names, seqs, width=70)
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    odb = oracle.OracleDB.from_arrays(HT, sz, ky, lb)
+    want_rows, _ = odb.query_rows(K, rp, con, 15)
+    want = oracle.result_rows(want_rows)
+    with _open(gpu, sz, ky, lb) as db:
+        got, rows = db.classify(rp, con, extended=True)
+        info = db.db_info()
+    assert np.array_equal(got, want)
+    assert np.array_equal(rows, want_rows)
+    assert info["n_keys"] == ky.size and info["line_bytes"] == 64
+    assert (want[:, 2] > 0).sum() > 1000
+
+
+@pytest.mark.parametrize("length", [21, 22, 84, 85, 86, 148, 149, 150, 151, 277, 501, 1000])
+def test_read_lengths_around_wave_boundaries(gpu, oracle, length):
+    """k-mers per read around 64 / 128 (one / two wave steps) and long reads"""
+    genomes, sz, ky, lb = small_db(glen=6000)
+    codes, _ = synth.sample_reads(genomes, 300, length, seed=length)
+    rp, con = synth.pack_uniform(codes)
+    want, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).classify(K, rp, con, 15)
+    with _open(gpu, sz, ky, lb) as db:
+        got = db.classify(rp, con)
+    assert np.array_equal(got, want)
+
+
+def test_empty_and_tiny_batches(gpu, oracle):
+    genomes, sz, ky, lb = small_db()
+    with _open(gpu, sz, ky, lb) as db:
+        got = db.classify(np.zeros(1, dtype=np.uint32), np.zeros(0, dtype=np.uint16))
+        assert got.shape == (0, 5)
+        # reads without any container (all shorter than k)
+        rp = np.zeros(6, dtype=np.uint32)
+        got = db.classify(rp, np.zeros(0, dtype=np.uint16))
+        assert np.array_equal(got, np.zeros((5, 5), dtype=np.uint16))
+        # a single read
+        codes, _ = synth.sample_reads(genomes, 1, 150, seed=1)
+        rp, con = synth.pack_uniform(codes)
+        want, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).classify(K, rp, con, 15)
+        assert np.array_equal(db.classify(rp, con), want)
+
+
+def test_long_multi_part_read_uses_unstaged_path(gpu, oracle):
+    """one read larger than a wave's LDS slice (contig-like, several parts)"""
+    genomes, sz, ky, lb = small_db(glen=30000, n_targets=4)
+    seq = b"N".join(synth.codes_to_ascii(g[:9000 + 13 * i]) for i, g in enumerate(genomes))
+    short = synth.codes_to_ascii(genomes[1][50:200])
+    text = synth.fasta_text([b"contig", b"r1", b"contig2", b"r2"], [seq, short, seq[::-1], short], width=80)
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    want_rows, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).query_rows(K, rp, con, 15)
+    with _open(gpu, sz, ky, lb) as db:
+        got, rows = db.classify(rp, con, extended=True)
+    assert np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
+    assert got[0, 0] > 30000
+
+
+def test_more_targets_than_maxhits(gpu, oracle):
+    """reference: undefined; ours: keep the maxhits smallest ids, count the read"""
+    genomes, sz, ky, lb = small_db(n_targets=12, glen=1500, shared=0)
+    seq = b"N".join(synth.codes_to_ascii(g[100:140]) for g in genomes)
+    text = synth.fasta_text([b"chimera", b"plain"], [seq, synth.codes_to_ascii(genomes[3][:150])])
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    want_rows, ovf = oracle.OracleDB.from_arrays(HT, sz, ky, lb).query_rows(K, rp, con, 5)
+    assert ovf == 1
+    with _open(gpu, sz, ky, lb, maxhits=5) as db:
+        got, rows = db.classify(rp, con, extended=True)
+        st = db.stats()
+    assert np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
+    assert st["reads_over_maxhits"] == 1
+
+
+def test_many_targets_per_read_above_64(gpu, oracle):
+    """more distinct targets than accumulator lanes: the 64 smallest ids survive"""
+    genomes, sz, ky, lb = small_db(n_targets=90, glen=400, shared=0)
+    order = [(i * 37) % 90 for i in range(90)]
+    seq = b"N".join(synth.codes_to_ascii(genomes[i][50:50 + 30 + (i % 7)]) for i in order)
+    text = synth.fasta_text([b"zoo"], [seq])
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    want_rows, ovf = oracle.OracleDB.from_arrays(HT, sz, ky, lb).query_rows(K, rp, con, 63)
+    with _open(gpu, sz, ky, lb, maxhits=63, ntargets=90) as db:
+        got, rows = db.classify(rp, con, extended=True)
+    assert ovf == 1 and np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
+
+
+@pytest.mark.parametrize("line", [64, 128])
+def test_dense_buckets_overflow_table(gpu, oracle, line, monkeypatch):
+    """heavily loaded table: buckets beyond a line's capacity go to the side table"""
+    ht = 4099
+    sz, ky, lb = synth.random_db(seed=2, htsize=ht, n_keys=60000, n_targets=40, k=K)   # ~14.6 / bucket
+    off = np.concatenate([[0], np.cumsum(sz.astype(np.int64))])
+    # reads made of stored k-mers (hits) and of random sequence (misses)
+    kmers = np.concatenate([ky[off[r]:off[r + 1]].astype(np.uint64) * np.uint64(ht) + np.uint64(r) for r in range(0, ht, 7)])
+    codes = np.zeros((kmers.size, 50), dtype=np.uint8)
+    rnd = synth.random_codes(77, kmers.size * 50).reshape(kmers.size, 50)
+    codes[:] = rnd
+    for j in range(K):
+        codes[:, 10 + j] = ((kmers >> np.uint64(2 * (K - 1 - j))) & np.uint64(3)).astype(np.uint8)
+    rp, con = synth.pack_uniform(codes)
+    want, _ = oracle.OracleDB.from_arrays(ht, sz, ky, lb).classify(K, rp, con, 15)
+    monkeypatch.setenv("MC_LINE_BYTES", str(line))
+    with _open(gpu, sz, ky, lb, ht=ht, ntargets=40) as db:
+        info = db.db_info()
+        got = db.classify(rp, con)
+    assert info["line_bytes"] == line and info["n_overflow_buckets"] > 0
+    assert np.array_equal(got, want)
+    assert (want[:, 2] > 0).mean() > 0.45
+
+
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_sharded_db_merge_result_equals_unsharded(gpu, oracle, shards):
+    """bucket-range shards -> sparse rows -> merge -> top-2 == single shard (one GPU
+    plays every shard in turn; the exchange itself is covered by test_distributed)"""
+    import torch
+    genomes, sz, ky, lb = small_db(n_targets=10)
+    codes, _ = synth.sample_reads(genomes, 3000, 150, seed=6)
+    rp, con = synth.pack_uniform(codes)
+    want, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).classify(K, rp, con, 15)
+    dev = torch.device("cuda:0")
+    rp_t = torch.from_numpy(rp.view(np.int32)).to(dev)
+    con_t = torch.from_numpy(con.view(np.int16)).to(dev)
+    n = rp.size - 1
+    acc = None
+    bounds = [HT * i // shards for i in range(shards + 1)]
+    for s in range(shards):
+        with _open(gpu, sz, ky, lb, shard=(bounds[s], bounds[s + 1])) as db:
+            rows = torch.zeros((n, db.row_len), dtype=torch.int16, device=dev)
+            db.query_device(rp_t, con_t, rows_t=rows, stream=torch.cuda.current_stream().cuda_stream)
+            if acc is None:
+                acc = rows
+            else:
+                db.merge_rows_device(acc, rows, acc, n, stream=torch.cuda.current_stream().cuda_stream)
+            if s == shards - 1:
+                fin = torch.zeros((n, 5), dtype=torch.int16, device=dev)
+                db.result_rows_device(acc, fin, n, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+    assert np.array_equal(fin.cpu().numpy().view(np.uint16), want)
+
+
+def test_light_table_k27_against_reference_golden(gpu, oracle, golden_dir):
+    """HTSIZE 57777779, k=27: the database the REFERENCE's own code built, and the
+    lookups the reference's hTable::find answered (tests/golden/db_light_k27.npz)"""
+    g = np.load(os.path.join(golden_dir, "db_light_k27.npz"), allow_pickle=False)
+    k, ht = int(g["k"]), int(g["htsize"])
+    sz = np.zeros(ht, dtype=np.uint8)
+    sz[g["nonzero_buckets"]] = g["nonzero_sizes"]
+    q = g["query_kmers"]
+    # one k-mer per read
+    codes = np.zeros((q.size, k), dtype=np.uint8)
+    for j in range(k):
+        codes[:, j] = ((q >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)).astype(np.uint8)
+    rp, con = synth.pack_uniform(codes)
+    with _open(gpu, sz, g["keys"], g["labels"], k=k, ht=ht, maxhits=23, ntargets=3) as db:
+        got = db.classify(rp, con)
+    found = g["query_found"].astype(bool)
+    assert np.array_equal(got[:, 2] > 0, found)
+    assert np.array_equal(got[found, 1] - 1, g["query_label"][found])
+    assert np.all(got[found, 0] == 1)
+
+
+def test_file_loader_and_sampling(gpu, oracle, tmp_path):
+    genomes, sz, ky, lb = small_db()
+    off = np.concatenate([[0], np.cumsum(sz.astype(np.int64))])
+    nzb = np.flatnonzero(sz)
+    canon = np.repeat(nzb, sz[nzb]).astype(np.uint64) + ky.astype(np.uint64) * np.uint64(HT)
+    base = str(tmp_path / "db_central_k21_t6_s1000003_m0.tsk")
+    oracle.db_write(base, HT, 4, canon, lb)
+    codes, _ = synth.sample_reads(genomes, 1500, 150, seed=12)
+    rp, con = synth.pack_uniform(codes)
+    from jn_cuclark_amd import CuClarkDB
+    for s in (1, 3):
+        want, _ = oracle.OracleDB.load(base, HT, 4, sampling=s).classify(K, rp, con, 15)
+        with CuClarkDB(k=K, numBatches=1, numTargets=6, device=0, htsize=HT, maxhits=15) as db:
+            assert db.read(base, modCollision=s) is True
+            got = db.classify(rp, con)
+        assert np.array_equal(got, want)
+        assert (want[:, 2] > 0).sum() > 500
+    with CuClarkDB(k=K, numBatches=1, numTargets=6, device=0, htsize=HT, maxhits=15) as db:
+        assert db.read(str(tmp_path / "nope")) is False     # caller rebuilds (CuCLARK_hh.hh:622-684)
+
+
+def test_batched_streaming_interface(gpu, oracle):
+    """several batches in flight through malloc/readyBatch/queryBatch/waitForBatch"""
+    genomes, sz, ky, lb = small_db()
+    nb = 5
+    from jn_cuclark_amd import CuClarkDB
+    with CuClarkDB(k=K, numBatches=nb, numTargets=6, device=0, htsize=HT, maxhits=15) as db:
+        db.read_arrays(sz, ky, lb)
+        assert db.swapDbParts() is True
+        batches = []
+        for b in range(nb):
+            codes, _ = synth.sample_reads(genomes, 700 + 13 * b, 150, seed=20 + b)
+            batches.append(synth.pack_uniform(codes))
+        rp_l, con_l, fin_l, _ = db.malloc(max(p.size for p, _ in batches), max(c.size for _, c in batches))
+        for b, (p, c) in enumerate(batches):
+            rp_l[b][: p.size] = p
+            con_l[b][: c.size] = c
+            db.readyBatch(b, p.size - 1, c.size)
+            assert db.queryBatch(b) is True
+        assert db.swapDbParts() is False
+        odb = oracle.OracleDB.from_arrays(HT, sz, ky, lb)
+        for b, (p, c) in enumerate(batches):
+            db.waitForBatch(b)
+            n = p.size - 1
+            want, _ = odb.classify(K, p, c, 15)
+            assert np.array_equal(fin_l[b][: n * 5].reshape(n, 5), want)
+        db.freeBatchMemory()
+
+
+def test_errors_are_reported_not_fatal(gpu):
+    from jn_cuclark_amd import CuClarkDB, McError
+    with pytest.raises(McError):
+        CuClarkDB(k=31, numBatches=1, numTargets=3, htsize=1000003)       # needs 8-byte keys
+    with pytest.raises(McError):
+        CuClarkDB(k=40, numBatches=1, numTargets=3)
+    with CuClarkDB(k=K, numBatches=1, numTargets=3, htsize=HT) as db:
+        with pytest.raises(McError):
+            db.malloc(10, 100)
+            db.readyBatch(0, 1, 3)
+            db.queryBatch(0)                                              # no database yet

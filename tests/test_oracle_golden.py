@@ -1,0 +1,82 @@
+"""CPU suite, part 1: the oracle against what the REFERENCE's own CPU code produced
+(tests/golden/*.npz, made by tests/golden/make_golden.py from oracle/_ref)."""
+import os
+
+import numpy as np
+import pytest
+
+from jn_cuclark_amd import synth
+
+
+def _load(golden_dir, name):
+    p = os.path.join(golden_dir, name)
+    if not os.path.exists(p):
+        pytest.skip("%s not generated" % name)
+    return np.load(p, allow_pickle=False)
+
+
+def test_kmer_value_and_revcomp_match_reference(oracle, golden_dir):
+    g = _load(golden_dir, "kmer_vectors.npz")
+    for k in (20, 27, 31, 32):
+        strs, fwd, rc = g["k%d_str" % k], g["k%d_fwd" % k], g["k%d_rc" % k]
+        for s, f, r in zip(strs, fwd, rc):
+            v = oracle.kmer_from_string(str(s), k)
+            assert v == int(f)
+            assert oracle.revcomp(v, k) == int(r)
+            assert oracle.canonical(v, k) == min(int(f), int(r))
+        # numpy twins used by the workload generators
+        assert np.array_equal(synth.revcomp(fwd, k), rc)
+
+
+@pytest.mark.parametrize("name", ["db_light_k27.npz", "db_full_k31.npz"])
+def test_discriminative_set_and_files_match_reference(oracle, golden_dir, name, tmp_path):
+    g = _load(golden_dir, name)
+    k, htsize = int(g["k"]), int(g["htsize"])
+    canon, lab = oracle.build_discriminative(g["occ_kmers"], g["occ_targets"], k, htsize)
+    # the reference wrote: per bucket ascending quotients + labels
+    assert canon.size == g["keys"].size
+    assert np.array_equal((canon // np.uint64(htsize)).astype(np.uint32), g["keys"])
+    assert np.array_equal(lab, g["labels"])
+    r = (canon % np.uint64(htsize)).astype(np.int64)
+    nz, cnt = np.unique(r, return_counts=True)
+    assert np.array_equal(nz.astype(np.uint32), g["nonzero_buckets"])
+    assert np.array_equal(cnt.astype(np.uint8), g["nonzero_sizes"])
+    # numpy builder used by the synthetic workloads agrees too
+    c2, l2 = synth.discriminative(g["occ_kmers"], g["occ_targets"], k)
+    sz, ky, lb = synth.db_from_kmers(c2, l2, htsize) if htsize < 10**8 else (None, None, None)
+    if sz is not None:
+        assert np.array_equal(ky, g["keys"]) and np.array_equal(lb, g["labels"])
+        assert np.array_equal(np.flatnonzero(sz).astype(np.uint32), g["nonzero_buckets"])
+    if htsize < 10**8:
+        # byte-identical files (sha256 of what the reference's hTable::write produced)
+        import hashlib
+        base = str(tmp_path / "db")
+        oracle.db_write(base, htsize, 4, canon, lab)
+        for ext, want in zip((".sz", ".ky", ".lb"), g["sha256"]):
+            assert hashlib.sha256(open(base + ext, "rb").read()).hexdigest() == str(want)
+        # and the oracle reads them back
+        db = oracle.OracleDB.load(base, htsize, 4)
+        f, l = db.lookup(k, int(g["query_kmers"][0]))
+        assert (int(f), l if f else 0) == (int(g["query_found"][0]), int(g["query_label"][0]))
+
+
+@pytest.mark.parametrize("name", ["db_light_k27.npz", "db_full_k31.npz"])
+def test_lookup_matches_reference_find(oracle, golden_dir, name):
+    """oracle lookup (restating CuClarkDB.cu:1189-1254) == reference hTable::find."""
+    g = _load(golden_dir, name)
+    k, htsize = int(g["k"]), int(g["htsize"])
+    if htsize > 10**8:
+        # full-size table: rebuild the CSR arrays sparsely would need 1.6 GB of sizes;
+        # allowed on CPU (a few seconds) but keep the suite light
+        sz = np.zeros(htsize, dtype=np.uint8)
+    else:
+        sz = np.zeros(htsize, dtype=np.uint8)
+    sz[g["nonzero_buckets"]] = g["nonzero_sizes"]
+    db = oracle.OracleDB.from_arrays(htsize, sz, g["keys"], g["labels"])
+    q, ef, el = g["query_kmers"], g["query_found"], g["query_label"]
+    for i in range(q.size):
+        f, l = db.lookup(k, int(q[i]))
+        assert int(f) == int(ef[i]), i
+        if f:
+            assert l == int(el[i]), i
+    db.close()
