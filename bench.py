@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s classified on the headline configuration of BASELINE.json.
+
+    python bench.py --gpus 1 --steps K --warmup W          (driver: torchrun for N > 1)
+
+Workload (config.workload, SURVEY.md section 8d config 3 = BASELINE configs[2]):
+cuCLARK full-size table (HTSIZE 1610612741 buckets), k = 31, ~6.4e9 k-mers of 4096
+targets resident in HBM (synthetic: background k-mers + the k-mers of 4096 synthetic
+genomes), 10 M x 150 bp reads per step (half sampled from the genomes with 1 %
+substitutions, half uniform random).  A "step" is one pass of the hot path over that
+batch: packed reads (already in HBM) -> k-mers -> canonical -> hash -> bucket probe ->
+per-target hit counts -> (best, second) per read, through the C ABI (mc_query_device).
+
+One JSON line on stdout (rank 0).  `value` is the whole-job rate with inputs resident
+in HBM.  `roofline` is for the query kernel (HBM-transaction bound, no MFMA);
+`cpu_baseline` is the oracle's restatement timed on the host cores (rank 0, N=1 only),
+on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+READ_LEN = 150
+K = 31
+HTSIZE = 1610612741            # reference src/parameters.hh:37
+MAXHITS = 15                   # reference src/parameters.hh:44
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per step per GPU")
+    ap.add_argument("--lam", type=float, default=3.75, help="background k-mers per bucket (Poisson mean)")
+    ap.add_argument("--targets", type=int, default=4096)
+    ap.add_argument("--genome-len", type=int, default=100_000)
+    ap.add_argument("--htsize", type=int, default=HTSIZE)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
+                    help="N>1: replica = DB on every GPU, reads split; shard = DB split by bucket "
+                         "range, every GPU sees every read, sparse rows exchanged over RCCL")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--verify", type=int, default=20000, help="reads checked against the oracle (0 = none)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from jn_cuclark_amd import CuClarkDB, synth_gpu
+
+    k, ht = args.k, args.htsize
+    shard_mode = world > 1 and args.mode == "shard"
+    shard = (ht * rank // world, ht * (rank + 1) // world) if shard_mode else (0, ht)
+
+    # ---- database in HBM ---------------------------------------------------------
+    t0 = time.time()
+    genomes = synth_gpu.make_genomes(args.targets, args.genome_len, seed=31, device=dev)
+    d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, k, ht, args.targets, args.lam, genomes=genomes,
+                                                shard=shard if shard_mode else None)
+    n_keys = int(d_keys.numel())
+    db = CuClarkDB(k=k, numBatches=1, numTargets=args.targets, device=local_rank, htsize=ht, maxhits=MAXHITS)
+    db.read_device(d_sz, d_keys, d_labels, shard=shard)
+    info = db.db_info()
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("db: %.2fe9 k-mers, %d-byte lines, %.1f GB in HBM, %.3f %% of buckets overflow, built in %.1fs"
+            % (n_keys / 1e9, info["line_bytes"], info["device_bytes"] / 1e9,
+               100.0 * info["n_overflow_buckets"] / (shard[1] - shard[0]), time.time() - t0))
+    nonempty = float((d_sz != 0).float().mean().item()) if rank == 0 else 0.0
+
+    # ---- reads in HBM ------------------------------------------------------------
+    n_reads = args.reads
+    read_seed = 32 if shard_mode else 32 + rank      # shards see the SAME batch
+    rp_t, con_t = synth_gpu.make_reads(genomes, n_reads, READ_LEN, seed=read_seed)
+    fin_t = torch.zeros((n_reads, 5), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    rows_t = None
+    if shard_mode:
+        rows_t = torch.zeros((n_reads, db.row_len), dtype=torch.int16, device=dev)
+        per = (n_reads + world - 1) // world
+        recv_t = torch.zeros((world, per, db.row_len), dtype=torch.int16, device=dev)
+        send_t = torch.zeros((world, per, db.row_len), dtype=torch.int16, device=dev)
+
+    def step():
+        if not shard_mode:
+            db.query_device(rp_t, con_t, final_t=fin_t, stream=stream)
+            return
+        # every GPU: partial sparse rows of ALL reads for its bucket range
+        db.query_device(rp_t, con_t, rows_t=rows_t, stream=stream)
+        # reduce-scatter by read range over xGMI: GPU j receives everyone's rows for reads
+        # [j*per, (j+1)*per), merges them and runs top-2 for those reads
+        send_t.view(-1, db.row_len)[:n_reads].copy_(rows_t)
+        dist.all_to_all_single(recv_t.view(-1), send_t.view(-1))
+        mine = min(per, max(0, n_reads - rank * per))
+        for j in range(1, world):
+            db.merge_rows_device(recv_t[0], recv_t[j], recv_t[0], mine, stream=stream)
+        db.result_rows_device(recv_t[0], fin_t, mine, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_ms_avg = sum(kern_ms) / len(kern_ms)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    total_reads = n_reads * args.steps * (1 if shard_mode else world)
+    value = total_reads / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        fin = fin_t.cpu().numpy().view(np.uint16)
+        st = db.stats()
+        kmers_per_read = READ_LEN - k + 1
+        hit_rate = float(fin[:, 0].astype(np.float64).mean()) / kmers_per_read if not shard_mode else float("nan")
+        assigned = float((fin[:, 1] > 0).mean())
+        # algorithmic bytes per read on the reference layout: 44 B in + 10 B out
+        # + per k-mer 8 B of bucket offsets + 4 B per non-empty bucket + 2 B label per hit
+        hr = 0.0 if hit_rate != hit_rate else hit_rate
+        bytes_per_read = 54.0 + kmers_per_read * (8.0 + 4.0 * nonempty + 2.0 * hr)
+        achieved = bytes_per_read * n_reads / (kern_ms_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("reads_per_launch") == n_reads and tj.get("line_bytes") == info["line_bytes"]:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mreads/s classified, 150bp k=31 RefSeq-bacteria-scale DB",
+            "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "cuCLARK full table HTSIZE=%d k=%d, %.2fe9 k-mers of %d targets in HBM "
+                            "(%d-byte bucket lines), %d x %dbp reads per step per GPU, inputs resident in HBM"
+                            % (ht, k, n_keys * (world if shard_mode else 1) / 1e9, args.targets,
+                               info["line_bytes"], n_reads, READ_LEN),
+                "reads_per_step": n_reads * (1 if shard_mode else world), "k": k, "htsize": ht,
+                "n_kmers_db": n_keys, "targets": args.targets, "maxhits": MAXHITS,
+                "parallelism": ("shard%d+all_to_all" % world) if shard_mode else ("replica%d" % world),
+                "kmer_hit_rate": None if hit_rate != hit_rate else round(hit_rate, 4),
+                "reads_assigned": round(assigned, 4), "reads_over_maxhits": st["reads_over_maxhits"],
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "mc::query_kernel<%d>" % info["line_bytes"],
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel_ms": round(kern_ms_avg, 4), "algorithmic_bytes_per_read": round(bytes_per_read, 1),
+                "probes_per_s": round(kmers_per_read * n_reads / (kern_ms_avg * 1e-3), 1),
+                "line_gather_GBs": round(kmers_per_read * n_reads * info["line_bytes"] / (kern_ms_avg * 1e-3) / 1e9, 2),
+            },
+        }
+
+        # ---- oracle: spot check + CPU baseline (rank 0, N = 1) ----------------------
+        if world == 1 and not (args.no_cpu_baseline and args.verify == 0):
+            from oracle import pyoracle
+            t1 = time.time()
+            sz_h = d_sz.cpu().numpy()
+            ky_h = d_keys.cpu().numpy().view(np.uint32)
+            lb_h = d_labels.cpu().numpy().view(np.uint16)
+            odb = pyoracle.OracleDB.from_arrays(ht, sz_h, ky_h, lb_h)
+            del sz_h, ky_h, lb_h
+            log("oracle database on host in %.1fs" % (time.time() - t1))
+            rp_h = rp_t.cpu().numpy().view(np.uint32)
+            con_h = con_t.cpu().numpy().view(np.uint16)
+            per_read = con_h.size // n_reads
+
+            def sample(idx0, m):
+                p = (np.arange(m + 1, dtype=np.uint64) * np.uint64(per_read)).astype(np.uint32)
+                return p, con_h[idx0 * per_read:(idx0 + m) * per_read]
+
+            if args.verify:
+                for idx0 in (0, n_reads - args.verify):      # planted half and random half
+                    p, c = sample(idx0, args.verify)
+                    want, _ = odb.classify(k, p, c, MAXHITS)
+                    if not np.array_equal(want, fin[idx0:idx0 + args.verify]):
+                        raise SystemExit("bench: HIP results differ from the oracle")
+                out["config"]["verified_reads_vs_oracle"] = 2 * args.verify
+            if not args.no_cpu_baseline:
+                cores = pyoracle.num_threads()
+                m = args.cpu_sample or 20000 * cores
+                m = min(m, n_reads // 2)
+                # half planted + half random, like the full batch
+                p, c1 = sample(0, m // 2)
+                _, c2 = sample(n_reads - m // 2, m // 2)
+                cc = np.concatenate([c1, c2])
+                pp = (np.arange(2 * (m // 2) + 1, dtype=np.uint64) * np.uint64(per_read)).astype(np.uint32)
+                odb.classify(k, pp[:2001], cc[:2000 * per_read], MAXHITS)     # warm
+                t1 = time.perf_counter()
+                odb.classify(k, pp, cc, MAXHITS)
+                dt = time.perf_counter() - t1
+                out["cpu_baseline"] = {
+                    "value": round(2 * (m // 2) / dt / 1e6, 4), "unit": "Mreads/s", "cores": cores,
+                    "kind": "port",
+                    "sample": "%d reads of the same batch (half genome-sampled, half random) against the "
+                              "same table on the host, OpenMP schedule(dynamic), %.1f s" % (2 * (m // 2), dt),
+                }
+            odb.close()
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    db.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,7 +145,7 @@ int mc_sync(mc_ctx *ctx);
 int mc_free_batches(mc_ctx *ctx);
 
 /* ---- device-resident entry points (inputs and outputs already in HBM) -------
- * `stream` is a hipStream_t (NULL = the ctx's first stream).  Used by the
+ * `stream` is a hipStream_t (NULL = the HIP default stream).  Used by the
  * multi-GPU path (rows travel over RCCL between the calls) and by bench.py. */
 
 /* queryKernel (+ fused resultKernel when MC_F_FINAL): CuClarkDB.cu:999-1254. */

@@ -607,8 +607,7 @@ int mc_query_device(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uin
     if ((flags & MC_F_FINAL) && !d_final) return fail(MC_EINVAL, "MC_F_FINAL without d_final_rows");
     if ((flags & MC_F_ROWS) && !d_rows) return fail(MC_EINVAL, "MC_F_ROWS without d_sparse_rows");
     int rc = set_dev(c); if (rc) return rc;
-    return launch_query(c, d_ptr, d_con, n_reads, n_con, flags, d_final, d_rows,
-                        stream ? (hipStream_t)stream : c->streams[0]);
+    return launch_query(c, d_ptr, d_con, n_reads, n_con, flags, d_final, d_rows, (hipStream_t)stream);
 }
 
 int mc_merge_rows_device(mc_ctx *c, const uint16_t *d_a, const uint16_t *d_b, uint64_t n_reads,
@@ -619,7 +618,7 @@ int mc_merge_rows_device(mc_ctx *c, const uint16_t *d_a, const uint16_t *d_b, ui
     if (n_reads == 0) return MC_OK;
     const uint32_t row_len = 2 * c->maxhits + 2;
     const uint32_t g = (uint32_t)((n_reads + 255) / 256);
-    hipLaunchKernelGGL(mc::merge_rows_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : c->streams[0],
+    hipLaunchKernelGGL(mc::merge_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
                        d_a, d_b, row_len, n_reads, d_out);
     HIPCHK(hipGetLastError());
     return MC_OK;
@@ -632,7 +631,7 @@ int mc_result_rows_device(mc_ctx *c, const uint16_t *d_rows, uint64_t n_reads, u
     if (n_reads == 0) return MC_OK;
     const uint32_t row_len = 2 * c->maxhits + 2;
     const uint32_t g = (uint32_t)((n_reads + 255) / 256);
-    hipLaunchKernelGGL(mc::result_rows_kernel, dim3(g), dim3(256), 0, stream ? (hipStream_t)stream : c->streams[0],
+    hipLaunchKernelGGL(mc::result_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream,
                        d_rows, row_len, n_reads, d_final);
     HIPCHK(hipGetLastError());
     return MC_OK;

@@ -1,0 +1,161 @@
+"""On-GPU synthetic workloads for bench.py.
+
+Plumbing only (torch for device memory and bulk integer ops, libmcsynth.so for the
+per-bucket generator): a bacteria-scale table is built in HBM in the array form of the
+on-disk format and handed to ``CuClarkDB.read_device`` -- the same re-layout path the
+file loader uses.  Reads are sampled from the synthetic genomes (with substitutions), so
+they hit runs of overlapping k-mers like real reads, mixed with uniform random reads.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SYN = None
+
+
+def _syn():
+    global _SYN
+    if _SYN is None:
+        path = os.path.join(_HERE, "libmcsynth.so")
+        if not os.path.exists(path):
+            raise ImportError("%s missing: run `make -C jn_cuclark_amd/csrc`" % path)
+        lib = C.CDLL(path)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        lib.mcs_last_error.restype = C.c_char_p
+        lib.mcs_counts_device.restype = C.c_int
+        lib.mcs_counts_device.argtypes = [u64, u32, u64, u32, C.c_double, u64, u64, vp, u64, vp, C.POINTER(u64), vp]
+        lib.mcs_fill_device.restype = C.c_int
+        lib.mcs_fill_device.argtypes = [u64, u32, u64, u32, C.c_double, u64, u64, vp, vp, vp, vp, u64, vp, vp, vp, vp, vp]
+        lib.mcs_bucket_host.restype = C.c_int
+        lib.mcs_bucket_host.argtypes = [u64, u32, u64, u32, C.c_double, u64, C.POINTER(u32), vp, vp]
+        _SYN = lib
+    return _SYN
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError("libmcsynth: %s" % _syn().mcs_last_error().decode())
+
+
+def _s64(x):
+    """python int (u64 bit pattern) -> signed int64 value"""
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def revcomp_t(x, k):
+    """torch int64 twin of the reverse complement (reference src/CuClarkDB.cu:1196-1203)."""
+    r = x
+    for sh, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF),
+                  (16, 0x0000FFFF0000FFFF)):
+        m = _s64(m)
+        r = ((r >> sh) & m) | ((r & m) << sh)
+    r = ((r >> 32) & 0xFFFFFFFF) | (r << 32)
+    s = 64 - 2 * k
+    return ((~r) >> s) & ((1 << (64 - s)) - 1) if s > 0 else ~r
+
+
+def kmers_t(codes, k):
+    """forward k-mers of every window of a [G, L] uint8 code tensor -> int64 [G, L-k+1] (k <= 31)"""
+    n = codes.shape[1] - k + 1
+    v = torch.zeros((codes.shape[0], n), dtype=torch.int64, device=codes.device)
+    for j in range(k):
+        v = (v << 2) | codes[:, j:j + n].to(torch.int64)
+    return v
+
+
+def make_genomes(n_targets, length, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randint(0, 4, (n_targets, length), dtype=torch.uint8, device=device, generator=g)
+
+
+def build_db(device, seed, k, htsize, n_targets, lam, genomes=None, shard=None):
+    """Returns (d_sz uint8[nb], d_keys int32[n], d_labels int16[n]) for buckets `shard`."""
+    lib = _syn()
+    b0, b1 = shard if shard else (0, htsize)
+    nb = b1 - b0
+    stream = torch.cuda.current_stream(device).cuda_stream
+    app_r = app_q = app_l = None
+    n_app = 0
+    if genomes is not None:
+        km = kmers_t(genomes, k)
+        lab = torch.arange(genomes.shape[0], device=device, dtype=torch.int16)[:, None].expand_as(km).reshape(-1)
+        km = km.reshape(-1)
+        c = torch.minimum(km, revcomp_t(km, k))
+        del km
+        r = c % htsize
+        q = c // htsize
+        del c
+        if shard:
+            keep = (r >= b0) & (r < b1)
+            r, q, lab = r[keep], q[keep], lab[keep]
+        app_r, app_q, app_l = r.contiguous(), q.contiguous(), lab.contiguous()
+        n_app = app_r.numel()
+    d_sz = torch.empty((nb + 3) // 4 * 4, dtype=torch.uint8, device=device)
+    n_keys = C.c_uint64()
+    _chk(lib.mcs_counts_device(seed, k, htsize, n_targets, lam, b0, nb,
+                               app_r.data_ptr() if n_app else None, n_app,
+                               d_sz.data_ptr(), C.byref(n_keys), stream))
+    n = n_keys.value
+    d_keys = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    d_labels = torch.empty(max(n, 1), dtype=torch.int16, device=device)
+    d_off = torch.empty(nb, dtype=torch.int64, device=device)
+    d_cur = torch.empty((nb + 3) // 4 * 4, dtype=torch.uint8, device=device)
+    _chk(lib.mcs_fill_device(seed, k, htsize, n_targets, lam, b0, nb, d_sz.data_ptr(),
+                             app_r.data_ptr() if n_app else None, app_q.data_ptr() if n_app else None,
+                             app_l.data_ptr() if n_app else None, n_app,
+                             d_off.data_ptr(), d_cur.data_ptr(), d_keys.data_ptr(), d_labels.data_ptr(), stream))
+    torch.cuda.synchronize(device)
+    del d_off, d_cur, app_r, app_q, app_l
+    return d_sz[:nb], d_keys[:n], d_labels[:n]
+
+
+def bucket_host(seed, k, htsize, n_targets, lam, bucket):
+    """CPU twin of the background generator: (keys u32[], labels u16[]) of one bucket."""
+    import numpy as np
+    cnt = C.c_uint32()
+    keys = np.zeros(64, dtype=np.uint32)
+    labs = np.zeros(64, dtype=np.uint16)
+    _chk(_syn().mcs_bucket_host(seed, k, htsize, n_targets, lam, bucket, C.byref(cnt),
+                                keys.ctypes.data, labs.ctypes.data))
+    return keys[:cnt.value].copy(), labs[:cnt.value].copy()
+
+
+def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, chunk=1 << 20):
+    """n_reads packed reads of `length` bases: the first planted_frac are windows of the
+    genomes with substitutions, the rest uniform random.  Returns (reads_ptr int32[n+1],
+    containers int16[n*(1+ceil(L/8))]) in the reference batch format
+    (src/CuCLARK_hh.hh:1615-1715): one part per read = [L][containers]."""
+    device = genomes.device
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    T, G = genomes.shape
+    nc = (length + 7) // 8
+    out = torch.empty((n_reads, nc + 1), dtype=torch.int16, device=device)
+    flat = genomes.reshape(-1)
+    n_planted = int(n_reads * planted_frac)
+    ar = torch.arange(length, device=device, dtype=torch.int64)[None, :]
+    sh = (14 - 2 * torch.arange(8, device=device, dtype=torch.int32))[None, None, :]
+    for s in range(0, n_reads, chunk):
+        e = min(n_reads, s + chunk)
+        m = e - s
+        n_pl = max(0, min(e, n_planted) - s)
+        codes = torch.randint(0, 4, (m, length), dtype=torch.uint8, device=device, generator=g)
+        if n_pl:
+            gi = torch.randint(0, T, (n_pl,), device=device, generator=g)
+            pos = torch.randint(0, G - length + 1, (n_pl,), device=device, generator=g)
+            win = flat[(gi * G + pos)[:, None] + ar]
+            mut = torch.rand((n_pl, length), device=device, generator=g) < sub_rate
+            delta = torch.randint(1, 4, (n_pl, length), dtype=torch.uint8, device=device, generator=g)
+            codes[:n_pl] = torch.where(mut, (win + delta) & 3, win)
+        pad = torch.zeros((m, nc * 8), dtype=torch.int32, device=device)
+        pad[:, :length] = codes
+        con = (pad.reshape(m, nc, 8) << sh).sum(dim=2)
+        out[s:e, 0] = length
+        out[s:e, 1:] = con.to(torch.int16)       # wraps to the u16 bit pattern
+    if n_reads * (nc + 1) >= 2 ** 32:
+        raise ValueError("batch exceeds the 32-bit container offsets of the batch format")
+    ptr = (torch.arange(n_reads + 1, device=device, dtype=torch.int64) * (nc + 1)).to(torch.int32)
+    return ptr, out.reshape(-1)
