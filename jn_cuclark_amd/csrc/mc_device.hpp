@@ -120,50 +120,86 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-// One probe's line, in registers.
+// ---------------------------------------------------------------------------
+// cooperative bucket probe
+//
+// A bucket line is fetched by LPP = LINE/16 adjacent lanes, 16 bytes each, so that one
+// probe is ONE coalesced LINE-byte request (one L1-TLB lookup, one TCP->L2 request, one
+// HBM fetch).  A wave step therefore takes LPP rounds: in round j the 64/LPP lane groups
+// serve the probes of owner lanes j*64/LPP ... and group lane `part` holds dwords
+// [4*part, 4*part+4) of the line.  (Measured on MI355X: a lane loading its whole line
+// with four 16-byte loads costs four requests + four TLB lookups per probe and 1.37 HBM
+// fetches per probe -- profiles/r01_v1_lane_per_probe_pmc.txt.)
+// ---------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int LINE> struct LineRegs { u32x4 v[LINE / 16]; };
+static constexpr uint32_t LIDX_NONE = 0xFFFFFFFFu;     // no probe for this lane
 
-template <int LINE>
-__device__ __forceinline__ void line_load(LineRegs<LINE> &L, const uint8_t *lines, uint64_t idx)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
-    const u32x4 *p = reinterpret_cast<const u32x4 *>(lines + idx * (uint64_t)LINE);
-#pragma unroll
-    for (int i = 0; i < LINE / 16; i++) L.v[i] = __builtin_nontemporal_load(p + i);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// minimum over the LPP lanes of a group, result in every lane of the group
+template <int LPP>
+__device__ __forceinline__ uint32_t group_min(uint32_t v)
+{
+    uint32_t w = dpp_u32<0xB1>(v);  v = w < v ? w : v;          // quad_perm [1,0,3,2]
+    w = dpp_u32<0x4E>(v);           v = w < v ? w : v;          // quad_perm [2,3,0,1]
+    if (LPP == 8) { w = dpp_u32<0x141>(v); v = w < v ? w : v; } // row_half_mirror
+    return v;
 }
 
 template <int LINE>
-__device__ __forceinline__ uint32_t line_dw(const LineRegs<LINE> &L, int i)
+__device__ __forceinline__ u32x4 part_load(const uint8_t *lines, uint32_t lidx, uint32_t part)
 {
-    return L.v[i >> 2][i & 3];
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(lines + (uint64_t)lidx * (uint64_t)LINE + part * 16u);
+    return __builtin_nontemporal_load(p);
 }
 
-// Lookup of quotient q in a loaded line.  Equivalent to the scan of reference
-// CuClarkDB.cu:1226-1250 for ascending distinct keys: the lowest matching index wins.
+// Evaluate one round: this lane holds dwords [4*part, 4*part+4) of the line of its
+// group's probe, whose quotient is q.  Returns hit/label for the group's probe (the
+// same value in every lane of the group).  Lowest matching index wins, like the
+// ascending scan of reference CuClarkDB.cu:1236-1247.
 template <int LINE>
-__device__ __forceinline__ bool line_find(const LineRegs<LINE> &L, uint32_t q,
+__device__ __forceinline__ bool part_find(const u32x4 v, uint32_t q, bool active, uint32_t lane,
                                           const uint32_t *ovf_keys, const uint16_t *ovf_labels,
                                           uint32_t &label)
 {
     using C = LineCfg<LINE>;
-    const uint32_t hdr = line_dw<LINE>(L, C::HDR) & 0xFFu;
-    bool hit = false;
-    if (hdr != HDR_OVERFLOW) {
+    constexpr int LPP = LINE / 16;
+    const uint32_t part = lane & (LPP - 1);
+    const uint32_t gbase = lane & ~(uint32_t)(LPP - 1);
+    uint32_t midx = 0xFFu;
 #pragma unroll
-        for (int i = C::CAP - 1; i >= 0; i--) {
-            const uint32_t key = line_dw<LINE>(L, i);
-            const uint32_t lw  = line_dw<LINE>(L, C::LAB0 + (i >> 1));
-            const uint32_t lab = (i & 1) ? (lw >> 16) : (lw & 0xFFFFu);
-            if (key == q) { hit = true; label = lab; }
+    for (int d = 3; d >= 0; d--) {
+        const uint32_t gd = part * 4u + (uint32_t)d;
+        if (active && gd < (uint32_t)C::CAP && v[d] == q) midx = gd;
+    }
+    midx = group_min<LPP>(midx);
+    // label dword of key midx: global dword CAP + midx/2 -> lane (that/4), register (that%4)
+    const uint32_t ld = (uint32_t)C::LAB0 + ((midx & 0x7Fu) >> 1);
+    const uint32_t sel = ld & 3u;
+    const uint32_t cand = sel == 0 ? v[0] : sel == 1 ? v[1] : sel == 2 ? v[2] : v[3];
+    const uint32_t lw = (uint32_t)__shfl((int)cand, (int)(gbase + (ld >> 2)), 64);
+    bool hit = midx != 0xFFu;
+    label = (midx & 1u) ? (lw >> 16) : (lw & 0xFFFFu);
+
+    // buckets that did not fit a line (header 0xFF): rare, handled by group lane 0
+    const bool ovf_here = active && part == (uint32_t)(LPP - 1) && (v[3] & 0xFFu) == HDR_OVERFLOW;
+    if (__ballot(ovf_here)) {
+        const bool ovf = __shfl((int)ovf_here, (int)(gbase + LPP - 1), 64) != 0;
+        uint32_t res = 0;                               // bit 16 = hit, low 16 = label
+        if (ovf && part == 0) {
+            const uint64_t off = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+            const uint32_t n = v[2];
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t key = ovf_keys[off + i];
+                if (key == q) { res = 0x10000u | ovf_labels[off + i]; break; }
+                if (key > q) break;
+            }
         }
-    } else {
-        const uint64_t off = (uint64_t)line_dw<LINE>(L, 0) | ((uint64_t)line_dw<LINE>(L, 1) << 32);
-        const uint32_t n   = line_dw<LINE>(L, 2);
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t key = ovf_keys[off + i];
-            if (key == q) { hit = true; label = ovf_labels[off + i]; break; }
-            if (key > q) break;
-        }
+        res = (uint32_t)__shfl((int)res, (int)gbase, 64);
+        if (ovf) { hit = (res >> 16) != 0; label = res & 0xFFFFu; }
     }
     return hit;
 }
@@ -245,16 +281,14 @@ void query_kernel(const QueryArgs a)
                 const uint32_t nk = plen - k + 1u;
 
                 for (uint32_t base = 0; base < nk; base += 128u) {
-                    bool     act[2];
-                    uint32_t q32[2];
-                    uint64_t lidx[2];
-                    LineRegs<LINE> L[2];
+                    constexpr int LPP = LINE / 16;        // lanes per probe
+                    constexpr int PPR = 64 / LPP;         // probes per round
+                    uint32_t q32[2], lidx[2];
 #pragma unroll
                     for (int s = 0; s < 2; s++) {
                         const uint32_t p = base + 64u * s + lane;
-                        act[s] = p < nk;
-                        q32[s] = 0; lidx[s] = 0;
-                        if (act[s]) {
+                        q32[s] = 0; lidx[s] = LIDX_NONE;
+                        if (p < nk) {
                             // 80-bit window = containers j0..j0+4, first base in the top bits
                             const uint32_t j0 = first + (p >> 3);
                             const uint64_t hi = ((uint64_t)con(j0) << 48) | ((uint64_t)con(j0 + 1) << 32)
@@ -268,21 +302,41 @@ void query_kernel(const QueryArgs a)
                             const uint64_t c  = x < rc ? x : rc;               // canonical (ref :1206)
                             const uint64_t q  = div_u64(c, a.div);
                             const uint64_t r  = c - q * a.div.d;
-                            act[s] = (r >= a.shard_begin) && (r < a.shard_end);   // ref :1212-1214
-                            q32[s] = (uint32_t)q;
-                            lidx[s] = r - a.shard_begin;
+                            if ((r >= a.shard_begin) && (r < a.shard_end)) {   // ref :1212-1214
+                                q32[s] = (uint32_t)q;
+                                lidx[s] = (uint32_t)(r - a.shard_begin);
+                            }
                         }
                     }
+                    // issue every line fetch of the step (2 slots x LPP rounds) before using any
+                    const uint32_t part = lane & (LPP - 1);
+                    uint32_t gq[2][LPP], gl[2][LPP];
+                    u32x4 gv[2][LPP];
 #pragma unroll
-                    for (int s = 0; s < 2; s++)
-                        if (act[s]) line_load<LINE>(L[s], a.lines, lidx[s]);
-
+                    for (int s = 0; s < 2; s++) {
+#pragma unroll
+                        for (int j = 0; j < LPP; j++) {
+                            const int src = j * PPR + (int)(lane / LPP);
+                            gq[s][j] = (uint32_t)__shfl((int)q32[s], src, 64);
+                            gl[s][j] = (uint32_t)__shfl((int)lidx[s], src, 64);
+                            gv[s][j] = u32x4{0u, 0u, 0u, 0u};
+                            if (gl[s][j] != LIDX_NONE) gv[s][j] = part_load<LINE>(a.lines, gl[s][j], part);
+                        }
+                    }
+                    // after the LPP rounds lane l holds the result of probe PPR*(l%LPP) + l/LPP:
+                    // a permutation of the step's probes, which is all the counting needs
                     bool     hit[2];
                     uint32_t lab[2];
 #pragma unroll
                     for (int s = 0; s < 2; s++) {
                         hit[s] = false; lab[s] = 0;
-                        if (act[s]) hit[s] = line_find<LINE>(L[s], q32[s], a.ovf_keys, a.ovf_labels, lab[s]);
+#pragma unroll
+                        for (int j = 0; j < LPP; j++) {
+                            uint32_t l = 0;
+                            const bool h = part_find<LINE>(gv[s][j], gq[s][j], gl[s][j] != LIDX_NONE, lane,
+                                                           a.ovf_keys, a.ovf_labels, l);
+                            if (part == (uint32_t)j) { hit[s] = h; lab[s] = l; }
+                        }
                     }
 
                     // fold the hits of this step into the accumulator, one distinct
