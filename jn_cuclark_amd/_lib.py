@@ -30,7 +30,8 @@ class McStats(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libmcclark.so")
+    # MC_LIB_PATH: A/B builds of the same ABI (kernel tuning); default = the in-tree build
+    return os.environ.get("MC_LIB_PATH") or os.path.join(_HERE, "libmcclark.so")
 
 
 # every symbol include/mc_api.h declares: (name, restype, argtypes)

@@ -221,6 +221,10 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint1
     else            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::query_kernel<128>, mc::BLOCK_THREADS, 0));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
+    if (const char *e = getenv("MC_GRID_OCC")) {          // tuning knob: resident workgroups per CU
+        const int v = atoi(e);
+        if (v >= 1 && v < occ) occ = v;
+    }
     c->grid_blocks = occ * c->n_cu;
     c->db_loaded = true;
     return MC_OK;
