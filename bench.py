@@ -75,7 +75,11 @@ def main():
 
     k, ht = args.k, args.htsize
     shard_mode = world > 1 and args.mode == "shard"
-    shard = (ht * rank // world, ht * (rank + 1) // world) if shard_mode else (0, ht)
+    if shard_mode:
+        from jn_cuclark_amd.dist import shard_range
+        shard = shard_range(ht, rank, world)
+    else:
+        shard = (0, ht)
 
     # ---- database in HBM ---------------------------------------------------------
     t0 = time.time()
@@ -99,27 +103,19 @@ def main():
     rp_t, con_t = synth_gpu.make_reads(genomes, n_reads, READ_LEN, seed=read_seed)
     fin_t = torch.zeros((n_reads, 5), dtype=torch.int16, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    rows_t = None
+    sharded = None
     if shard_mode:
-        rows_t = torch.zeros((n_reads, db.row_len), dtype=torch.int16, device=dev)
-        per = (n_reads + world - 1) // world
-        recv_t = torch.zeros((world, per, db.row_len), dtype=torch.int16, device=dev)
-        send_t = torch.zeros((world, per, db.row_len), dtype=torch.int16, device=dev)
+        from jn_cuclark_amd.dist import ShardedClassifier, HipBackend
+        sharded = ShardedClassifier(HipBackend(db, dev))
 
     def step():
         if not shard_mode:
             db.query_device(rp_t, con_t, final_t=fin_t, stream=stream)
             return
-        # every GPU: partial sparse rows of ALL reads for its bucket range
-        db.query_device(rp_t, con_t, rows_t=rows_t, stream=stream)
-        # reduce-scatter by read range over xGMI: GPU j receives everyone's rows for reads
-        # [j*per, (j+1)*per), merges them and runs top-2 for those reads
-        send_t.view(-1, db.row_len)[:n_reads].copy_(rows_t)
-        dist.all_to_all_single(recv_t.view(-1), send_t.view(-1))
-        mine = min(per, max(0, n_reads - rank * per))
-        for j in range(1, world):
-            db.merge_rows_device(recv_t[0], recv_t[j], recv_t[0], mine, stream=stream)
-        db.result_rows_device(recv_t[0], fin_t, mine, stream=stream)
+        # every GPU: partial sparse rows of ALL reads for its bucket range, then a
+        # reduce-scatter by read range over xGMI (all_to_all), merge + top-2 on the owner
+        fin, (lo, hi) = sharded.classify(rp_t, con_t, n_reads)
+        fin_t[: hi - lo] = fin
 
     def barrier():
         torch.cuda.synchronize()
@@ -222,8 +218,9 @@ def main():
                         raise SystemExit("bench: HIP results differ from the oracle")
                 out["config"]["verified_reads_vs_oracle"] = 2 * args.verify
             if not args.no_cpu_baseline:
-                cores = pyoracle.num_threads()
-                m = args.cpu_sample or 20000 * cores
+                cores = pyoracle.host_cores()
+                pyoracle.set_num_threads(cores)
+                m = args.cpu_sample or 100000 * cores
                 m = min(m, n_reads // 2)
                 # half planted + half random, like the full batch
                 p, c1 = sample(0, m // 2)

@@ -1,0 +1,203 @@
+// dbbuild.hpp -- targets definition + database build (CPU; BASELINE config 1 plumbing).
+//
+// Semantics follow the reference builder (src/CuCLARK_hh.hh:690-1329 with
+// src/HashTableStorage_hh.hh:421-461 addElement, :229-280 RemoveCommon and
+// src/hashTable_hh.hh:473-546 write) but not its data structure: the reference fills a
+// chained table of HTSIZE vectors (25.8 GB for the full table before the first k-mer);
+// here every occurrence becomes a (bucket, quotient, target) triple, the triples are
+// sorted, and a run scan keeps the k-mers seen in exactly one target.  The three
+// files (.sz/.ky/.lb) come out byte-identical (tests/test_host_cli.py,
+// tests/test_oracle_golden.py pin the same rule against the reference's own output).
+#pragma once
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace host {
+
+struct Targets {
+    std::vector<std::pair<std::string, std::string>> files;  // (path, label)   m_targetsID
+    std::vector<std::string> labels;                         // unique labels   m_labels
+    std::vector<std::string> names;                          // "NA" + labels   m_targetsName
+};
+
+// split on ' ' ',' '\n' '\t' '\r', at most `max` elements (src/file.cc:63-87)
+inline std::vector<std::string> split_line(const std::string &line, size_t max)
+{
+    std::vector<std::string> out;
+    size_t t = 0, n = line.size();
+    auto sep = [](char c) { return c == ' ' || c == ',' || c == '\n' || c == '\t' || c == '\r'; };
+    while (t < n && out.size() < max) {
+        while (t < n && sep(line[t])) t++;
+        std::string v;
+        while (t < n && !sep(line[t])) v.push_back(line[t++]);
+        if (!v.empty()) out.push_back(v);
+    }
+    return out;
+}
+
+// reference getTargetsData, src/CuCLARK_hh.hh:1789-1901: "<file> <label>" per line
+inline bool read_targets(const char *path, Targets &T, std::string &err)
+{
+    FILE *f = std::fopen(path, "r");
+    if (!f) { err = std::string("Failed to open targets data in file: ") + path; return false; }
+    char *line = nullptr;
+    size_t cap = 0;
+    while (getline(&line, &cap, f) != -1) {
+        std::string l(line);
+        if (!l.empty() && l.back() == '\n') l.pop_back();
+        auto e = split_line(l, 3);
+        if (e.empty()) continue;
+        if (e.size() < 2) { err = " Missing label for " + e[0]; std::free(line); std::fclose(f); return false; }
+        if (!file_readable(e[0].c_str())) {
+            err = "Failed to open file: " + e[0] + " defined in " + path;
+            std::free(line); std::fclose(f); return false;
+        }
+        T.files.emplace_back(e[0], e[1]);
+        if (std::find(T.labels.begin(), T.labels.end(), e[1]) == T.labels.end()) T.labels.push_back(e[1]);
+    }
+    std::free(line);
+    std::fclose(f);
+    T.names.clear();
+    T.names.push_back("NA");
+    for (auto &s : T.labels) T.names.push_back(s);
+    return true;
+}
+
+// reference getdbName, src/CuCLARK_hh.hh:580-592 (folder already ends in '/')
+inline std::string db_name(const std::string &folder, unsigned k, size_t n_labels, unsigned min_count, unsigned gap)
+{
+    char buf[4096];
+    if (LIGHT)
+        std::snprintf(buf, sizeof buf, "%s/db_central_k%lu_t%lu_s%lu_m%lu_light_%lu.tsk", folder.c_str(),
+                      (unsigned long)k, (unsigned long)n_labels, (unsigned long)HTSIZE, (unsigned long)min_count,
+                      (unsigned long)gap);
+    else
+        std::snprintf(buf, sizeof buf, "%s/db_central_k%lu_t%lu_s%lu_m%lu.tsk", folder.c_str(), (unsigned long)k,
+                      (unsigned long)n_labels, (unsigned long)HTSIZE, (unsigned long)min_count);
+    return buf;
+}
+
+struct Occ { uint64_t r, q; uint16_t t; };
+
+// k-mers of one target file.  FASTA: every window of k valid bases (full variant,
+// :1127-1180), or -- light variant -- consecutive NON-overlapping windows of which
+// every gap-th is kept (:707-760).  Any non-ACGTU byte except '\n' resets the window;
+// '>' skips its header line.  FASTQ: the sequence line of each 4-line record.
+inline bool collect_file(const std::string &path, uint16_t target, unsigned k, unsigned gap,
+                         std::vector<Occ> &out, uint64_t &nt, std::string &err)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) { err = "Failed to open " + path; return false; }
+    std::vector<unsigned char> buf;
+    {
+        unsigned char tmp[1 << 16];
+        size_t g;
+        while ((g = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + g);
+    }
+    std::fclose(f);
+    if (buf.empty()) return true;
+    const bool fasta = buf[0] == '>', fastq = buf[0] == '@';
+    if (!fasta && !fastq) { err = path + ": spectrum-form targets are not supported by this build"; return false; }
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const auto &ct = codes();
+    uint64_t km = 0, iter = 0;
+    unsigned cpt = 0;
+    auto emit = [&](uint64_t x) {
+        const uint64_t c = canonical(x, k);
+        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target});
+    };
+    size_t i = 0, n = buf.size();
+    auto skip_line = [&]() { while (i < n && buf[i] != '\n') i++; i++; };
+    if (fastq) skip_line();
+    while (i < n) {
+        const unsigned char c = buf[i];
+        const int code = ct.r[c];
+        if (code >= 0) {
+            nt++;
+            km = ((km << 2) | (uint64_t)code) & mask;
+            cpt++;
+            if (cpt >= k) {
+                if (LIGHT) {
+                    if (iter % gap == 0) emit(km);
+                    iter++; km = 0; cpt = 0;
+                } else {
+                    emit(km);
+                    cpt = k;
+                }
+            }
+            i++;
+            continue;
+        }
+        if (c == '\n') {
+            if (fastq) { km = 0; cpt = 0; i++; skip_line(); skip_line(); skip_line(); }
+            else i++;
+            continue;
+        }
+        if (fasta && c == '>') { km = 0; cpt = 0; skip_line(); continue; }
+        nt++; km = 0; cpt = 0; i++;          // N and friends
+    }
+    return true;
+}
+
+// Build and write <base>.sz/.ky/.lb.  Returns the number of stored k-mers.
+inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned min_count, int key_bytes,
+                           const std::string &base, uint64_t &stored, std::string &err)
+{
+    std::vector<Occ> occ;
+    uint64_t nt = 0;
+    for (size_t t = 0; t < T.files.size(); t++) {
+        const auto it = std::find(T.labels.begin(), T.labels.end(), T.files[t].second);
+        const uint16_t id = (uint16_t)(it - T.labels.begin());
+        if (!collect_file(T.files[t].first, id, k, gap, occ, nt, err)) return false;
+        std::fprintf(stderr, "\r Progress report: (%zu/%zu)    ", t + 1, T.files.size());
+    }
+    std::fprintf(stderr, "%lu nt read in total.\n", (unsigned long)nt);
+    std::sort(occ.begin(), occ.end(), [](const Occ &a, const Occ &b) {
+        if (a.r != b.r) return a.r < b.r;
+        if (a.q != b.q) return a.q < b.q;
+        return a.t < b.t;
+    });
+    FILE *fs = std::fopen((base + ".sz").c_str(), "wb");
+    FILE *fk = std::fopen((base + ".ky").c_str(), "wb");
+    FILE *fl = std::fopen((base + ".lb").c_str(), "wb");
+    if (!fs || !fk || !fl) { err = "Failed to create " + base + ".*"; return false; }
+    // sizes are streamed in chunks; a bucket over 255 cannot be stored (hashTable_hh.hh:498-506)
+    const uint64_t CH = 1ull << 22;
+    std::vector<uint8_t> szbuf(CH);
+    size_t i = 0, n = occ.size();
+    size_t distinct = 0;
+    stored = 0;
+    for (uint64_t b0 = 0; b0 < HTSIZE; b0 += CH) {
+        const uint64_t b1 = std::min<uint64_t>(HTSIZE, b0 + CH);
+        std::fill(szbuf.begin(), szbuf.end(), 0);
+        while (i < n && occ[i].r < b1) {
+            size_t j = i;
+            bool multi = false;
+            while (j < n && occ[j].r == occ[i].r && occ[j].q == occ[i].q) { multi |= occ[j].t != occ[i].t; j++; }
+            distinct++;
+            if (!multi && (j - i) > min_count) {      // multiplicity 1 and count > minCount
+                uint8_t &s = szbuf[occ[i].r - b0];
+                if (s == 255) { err = "This table can not be stored on disk: Some bucket list size exceeds 255."; return false; }
+                s++;
+                if (key_bytes == 2) { uint16_t v = (uint16_t)occ[i].q; std::fwrite(&v, 2, 1, fk); }
+                else if (key_bytes == 4) { uint32_t v = (uint32_t)occ[i].q; std::fwrite(&v, 4, 1, fk); }
+                else std::fwrite(&occ[i].q, 8, 1, fk);
+                std::fwrite(&occ[i].t, 2, 1, fl);
+                stored++;
+            }
+            i = j;
+        }
+        std::fwrite(szbuf.data(), 1, b1 - b0, fs);
+    }
+    std::fclose(fs); std::fclose(fk); std::fclose(fl);
+    std::fprintf(stderr, "Mother Hashtable successfully built. %zu %u-mers stored.\n", distinct, k);
+    std::fprintf(stderr, "%lu %u-mers successfully stored in database.\n", (unsigned long)stored, k);
+    return true;
+}
+
+} // namespace host

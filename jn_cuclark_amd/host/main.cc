@@ -1,0 +1,369 @@
+// main.cc -- cuCLARK / cuCLARK-l compatible host driver over the C ABI.
+//
+// Same command line as the reference binary (src/main.cc:43-69, :103-212) so that an
+// unmodified scripts/classify_metagenome.sh (:155-159) can exec it:
+//   cuCLARK[-l] -k <k> -T <targets> -D <dbdir> (-O <file> | -P <f1> <f2>) -R <result>
+//               [-t <minfreq>] [-n <threads>] [-b <batches>] [-d <devices>] [-g <gap>]
+//               [-s <sampling>] [--tsk] [--extended] [--verbose]
+// Output: <result>.csv with the reference's columns and number formatting
+// (src/CuCLARK_hh.hh:1945-2122).  GPU work: include/mc_api.h only.
+//
+// Differences from the reference, all outside the per-read results:
+//   * -d N runs N replicas (whole table on every GPU, batches round-robin) instead of
+//     sharding a table that does not fit one Jetson; the sharded multi-GPU path is the
+//     process-per-GPU driver (jn_cuclark_amd/dist.py).
+//   * --tsk (.ht dumps) and spectrum-form targets are not implemented.
+#include "../../include/mc_api.h"
+#include "common.hpp"
+#include "dbbuild.hpp"
+#include "reads.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace host;
+
+namespace {
+
+void print_usage()
+{
+    std::cout << "\ncuCLARK" << (LIGHT ? "-l" : "") << " (MI355X build) -- metagenomic classification with discriminative k-mers\n\n"
+              << "./cuCLARK" << (LIGHT ? "-l" : "")
+              << " -k <kmerSize> -t <minFreqTarget> -T <fileTargets> -D <directoryDB/> -O <fileObjects> -R <fileResults>"
+                 " -n <numberofthreads> -b <numberofbatches> -d <numberofdevices> ...\n\n"
+              << "-k <kmerSize>,       k-mer length: integer, >= 2 and <= 32 (fixed to 27 for cuCLARK-l)\n"
+              << "-t <minFreqTarget>,  minimum of k-mer frequency in targets (default 0)\n"
+              << "-T <fileTargets>,    targets definition: filename, label per line\n"
+              << "-D <directoryDB/>,   directory of the database\n"
+              << "-O <fileObjects>,    objects (reads) in fasta/fastq, or a file listing such files\n"
+              << "-P <file1> <file2>,  paired-end fastq files\n"
+              << "-R <fileResults>,    results file (\".csv\" is appended), or a file listing result names\n"
+              << "-n <numberofthreads>, -b <numberofbatches>, -d <numberofdevices>\n"
+              << "-g <gap> (light only), -s <samplingFactor>, --extended, --verbose, --version, --help\n\n";
+}
+
+[[noreturn]] void die(const std::string &m, int code = 1)
+{
+    std::cerr << m << std::endl;
+    std::exit(code);
+}
+
+void mc_check(int rc, const char *what)
+{
+    if (rc != MC_OK) die(std::string(what) + ": " + mc_last_error());
+}
+
+struct Options {
+    size_t k = 31, cpu = 1, gap = 0, batches = 1, devices = 0;
+    unsigned minT = 0, sfactor = 1;
+    bool ext = false, verbose = false, tsk = false;
+    const char *targets = nullptr, *folder = nullptr, *objects = nullptr, *objects2 = nullptr, *results = nullptr;
+    const char *dump = nullptr;      // test hook: write the packed batches here
+};
+
+struct Classifier {
+    Options opt;
+    Targets T;
+    std::string folder, dbbase;
+    int key_bytes = 4;
+    std::vector<mc_ctx *> ctx;
+    bool paired = false;
+    size_t n_objects = 0;
+
+    void open_devices()
+    {
+        int n = 0;
+        if (mc_device_count(&n) != MC_OK || n < 1) die("No HIP devices found. Abort.");
+        if ((size_t)n < opt.devices) die(std::to_string(opt.devices) + " devices requested. Insufficient devices found. Abort.");
+        const size_t use = opt.devices ? opt.devices : 1;
+        for (size_t d = 0; d < use; d++) {
+            mc_ctx *c = nullptr;
+            mc_check(mc_open(&c, (int)d, (uint32_t)opt.k, HTSIZE, (uint32_t)(T.names.size() - 1), MAXHITS), "mc_open");
+            ctx.push_back(c);
+        }
+    }
+
+    // the database is built on the CPU when its files are missing (reference
+    // CuCLARK ctor, src/CuCLARK_hh.hh:306-311) -- before any GPU is touched
+    void build_if_missing()
+    {
+        dbbase = db_name(folder, (unsigned)opt.k, T.labels.size(), opt.minT, (unsigned)opt.gap);
+        const bool present = file_readable((dbbase + ".sz").c_str()) && file_readable((dbbase + ".ky").c_str()) &&
+                             file_readable((dbbase + ".lb").c_str());
+        if (present) return;
+        std::cerr << "Starting the creation of the database of targets specific " << opt.k
+                  << "-mers from input files..." << std::endl;
+        uint64_t stored = 0;
+        std::string err;
+        std::cerr << "Creating database in disk..." << std::endl;
+        if (!build_database(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err)) die(err, -1);
+    }
+
+    void load()
+    {
+        if (opt.verbose) std::cerr << "Loading database [" << dbbase << ".*] (s=" << opt.sfactor << ")..." << std::endl;
+        for (auto *c : ctx) {
+            const int rc = mc_load_db(c, dbbase.c_str(), key_bytes, opt.sfactor, 0, 0);
+            if (rc == MC_EIO) die("Failed to find the database.", -1);
+            mc_check(rc, "mc_load_db");
+        }
+        if (opt.verbose) {
+            mc_db_info info;
+            mc_get_db_info(ctx[0], &info);
+            std::cerr << "Total DB size in HBM:\t" << info.device_bytes / 1000000 / 1000.0 << " GB (" << info.n_keys
+                      << " k-mers, " << info.line_bytes << "-byte bucket lines)\n";
+            std::cerr << "DB loaded.\n";
+        } else {
+            std::cerr << "CuCLARK initialized.\n";
+        }
+    }
+
+    // one input file -> one CSV (reference runSimple + getObjectsDataComputeFullGPU + print*)
+    void run_simple(const char *objects, const char *result)
+    {
+        std::cerr << "Classifying: " << objects << "\n";
+        struct stat st;
+        const int fd = open(objects, O_RDONLY);
+        if (fd == -1 || fstat(fd, &st) != 0 || st.st_size == 0) { std::cerr << "Failed to open " << objects << std::endl; if (fd != -1) close(fd); return; }
+        const size_t nb = (size_t)st.st_size;
+        const uint8_t *map = (const uint8_t *)mmap(nullptr, nb, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (map == MAP_FAILED) { close(fd); std::cerr << "Failed to mmapping the file." << std::endl; return; }
+        const std::string csv = std::string(result) + ".csv";
+        FILE *fout = std::fopen(csv.c_str(), "w");
+        if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; munmap((void *)map, nb); close(fd); return; }
+
+        struct timeval t0, t1;
+        gettimeofday(&t0, nullptr);
+
+        ReadIndex R;
+        std::string err;
+        if (!index_reads(map, nb, R, err)) { std::cerr << err << std::endl; std::exit(-1); }
+        n_objects = R.size();
+        const size_t nbatch = std::max<size_t>(1, std::min(opt.batches, n_objects));
+        std::vector<size_t> first(nbatch + 1);
+        for (size_t b = 0; b <= nbatch; b++) first[b] = n_objects * b / nbatch;
+        size_t max_reads = 1, max_con = 8;
+        for (size_t b = 0; b < nbatch; b++) {
+            max_reads = std::max(max_reads, first[b + 1] - first[b]);
+            max_con = std::max(max_con, container_bound(R, first[b], first[b + 1], (unsigned)opt.k));
+        }
+        if (max_con > 0xFFFFFFFFull) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).", -1);
+
+        // batches are dealt round-robin to the devices; per device they are numbered 0..
+        const size_t ndev = ctx.size();
+        std::vector<uint32_t> per_dev(ndev, 0);
+        std::vector<std::pair<size_t, uint32_t>> where(nbatch);
+        for (size_t b = 0; b < nbatch; b++) { where[b] = {b % ndev, per_dev[b % ndev]++}; }
+        for (size_t d = 0; d < ndev; d++)
+            if (per_dev[d]) mc_check(mc_alloc_batches(ctx[d], per_dev[d], max_reads, max_con, opt.ext ? 1 : 0), "mc_alloc_batches");
+
+        const uint32_t flags = MC_F_FINAL | (opt.ext ? MC_F_ROWS : 0);
+        std::vector<size_t> ncon(nbatch, 0);
+        FILE *dump = opt.dump ? std::fopen(opt.dump, "wb") : nullptr;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+        for (long b = 0; b < (long)nbatch; b++) {
+            uint32_t *ptr; uint16_t *con;
+            mc_check(mc_batch_buffers(ctx[where[b].first], where[b].second, &ptr, &con, nullptr, nullptr), "mc_batch_buffers");
+            ncon[b] = pack_reads(map, R, first[b], first[b + 1], (unsigned)opt.k, ptr, con);
+#ifdef _OPENMP
+#pragma omp critical(submit)
+#endif
+            {
+                mc_check(mc_submit(ctx[where[b].first], where[b].second, first[b + 1] - first[b], ncon[b], flags), "mc_submit");
+            }
+        }
+        if (dump) {
+            for (size_t b = 0; b < nbatch; b++) {
+                uint32_t *ptr; uint16_t *con;
+                mc_batch_buffers(ctx[where[b].first], where[b].second, &ptr, &con, nullptr, nullptr);
+                const uint64_t n = first[b + 1] - first[b], c = ncon[b];
+                std::fwrite(&n, 8, 1, dump); std::fwrite(&c, 8, 1, dump);
+                std::fwrite(ptr, 4, n + 1, dump); std::fwrite(con, 2, c, dump);
+            }
+            std::fclose(dump);
+        }
+
+        // header (reference :1951-1967)
+        std::fputs("Object_ID", fout);
+        if (opt.ext) for (size_t t = 1; t < T.names.size(); t++) std::fprintf(fout, ",%s", T.names[t].c_str());
+        std::fputs(",Gamma,Assignment,Score,Confidence\n", fout);
+        std::cerr << (opt.ext ? "Writing extended results... " : "Writing results... ") << std::endl;
+
+        const size_t row_len = 2 * (size_t)MAXHITS + 2;
+        long nz_min = (long)T.names.size() - 1, nz_max = 0, nz_sum = 0;
+        std::string cells;
+        for (size_t b = 0; b < nbatch; b++) {
+            mc_check(mc_wait(ctx[where[b].first], where[b].second), "mc_wait");
+            uint16_t *fin, *rows;
+            mc_batch_buffers(ctx[where[b].first], where[b].second, nullptr, nullptr, &fin, &rows);
+            for (size_t i = first[b]; i < first[b + 1]; i++) {
+                const uint16_t *r5 = fin + (i - first[b]) * MC_FINAL_ROW;
+                const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
+                char name[OBJECTNAMEMAX];
+                size_t nl = R.name_e[i] - R.name_s[i];
+                if (nl >= OBJECTNAMEMAX) nl = OBJECTNAMEMAX - 1;
+                std::memcpy(name, map + R.name_s[i], nl);
+                name[nl] = '\0';
+                const uint32_t norm = (uint32_t)(paired ? R.len[i] - NBN : R.len[i]);     // ITYPE objectNorm
+                const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
+                double delta = (double)(best + s_best);
+                delta = (delta < 0.001) ? 0 : ((double)best) / delta;
+                const char *assign = ibest < T.names.size() ? T.names[ibest].c_str() : "NA";
+                if (!opt.ext) {
+                    std::fprintf(fout, "%s,%g,%s,%u,%g\n", name, gamma, assign, best, delta);
+                } else {
+                    // all scores, zeros for the targets not hit (reference :2006-2026)
+                    const uint16_t *row = rows + (i - first[b]) * row_len;
+                    cells.clear();
+                    size_t w = 0;
+                    for (uint32_t h = 0; h < row[0]; h++) {
+                        const size_t t = row[1 + 2 * h];
+                        for (; w < t; w++) cells += ",0";
+                        cells += ","; cells += std::to_string(row[2 + 2 * h]);
+                        w++;
+                    }
+                    for (; w < T.names.size() - 1; w++) cells += ",0";
+                    std::fprintf(fout, "%s%s,%g,%s,%u,%g\n", name, cells.c_str(), gamma, assign, best, delta);
+                    nz_max = std::max<long>(nz_max, row[0]); nz_min = std::min<long>(nz_min, row[0]); nz_sum += row[0];
+                }
+            }
+        }
+        std::fclose(fout);
+        std::cerr << "Done." << std::endl;
+        if (opt.ext && n_objects)
+            std::cerr << "MIN targets: " << nz_min << ", MAX targets: " << nz_max << ", AVG targets: "
+                      << (float)nz_sum / n_objects << "\n";
+        for (size_t d = 0; d < ndev; d++) if (per_dev[d]) mc_free_batches(ctx[d]);
+
+        gettimeofday(&t1, nullptr);
+        const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "Done in %.1fs (%zu reads/min, %zu reads)\n", diff,
+                      (size_t)(((double)n_objects) / diff * 60.0), n_objects);
+        std::cerr << buf << "Results: " << csv << "\n";
+        munmap((void *)map, nb);
+        close(fd);
+    }
+
+    static bool looks_like_sequence_file(const char *path)
+    {
+        std::ifstream f(path);
+        std::string line;
+        std::getline(f, line);
+        if (!line.empty() && (line[0] == '>' || line[0] == '@')) return true;
+        return split_line(line, 4).size() == 2;     // reference run(): "ele.size() == 2"
+    }
+
+    // reference run() single/paired with their "file of files" mode (:383-506)
+    void run()
+    {
+        if (!opt.objects2) {
+            paired = false;
+            if (!file_readable(opt.results) || looks_like_sequence_file(opt.objects)) { run_simple(opt.objects, opt.results); return; }
+            std::ifstream o(opt.objects), r(opt.results);
+            std::string ol, rl;
+            while (std::getline(o, ol) && std::getline(r, rl)) run_simple(ol.c_str(), rl.c_str());
+            return;
+        }
+        paired = true;
+        auto one = [&](const char *f1, const char *f2, const char *res) {
+            const std::string merged = std::string(f1) + "_ConcatenatedByCLARK.fa";
+            std::string err;
+            if (!merge_paired(f1, f2, merged.c_str(), err)) { perror(err.c_str()); std::exit(1); }
+            run_simple(merged.c_str(), res);
+            std::remove(merged.c_str());
+        };
+        if (!file_readable(opt.results) || looks_like_sequence_file(opt.objects)) { one(opt.objects, opt.objects2, opt.results); return; }
+        std::ifstream o1(opt.objects), o2(opt.objects2), r(opt.results);
+        std::string a, b, rl;
+        while (std::getline(o1, a) && std::getline(o2, b) && std::getline(r, rl)) one(a.c_str(), b.c_str(), rl.c_str());
+    }
+};
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc == 2) {
+        const std::string v(argv[1]);
+        if (v == "--help" || v == "--HELP") { print_usage(); return 0; }
+        if (v == "--version" || v == "--VERSION") {
+            std::cout << "Version: " << MC_HOST_VERSION << " (MI355X-native build of the cuCLARK classification path)" << std::endl;
+            return 0;
+        }
+    }
+    if (argc < 6) {
+        std::cerr << "To run " << argv[0] << ", at least four  parameters are necessary:\n"
+                  << "filename of the targets definition, directory of database, filename for objects, filename for results." << std::endl;
+        print_usage();
+        return -1;
+    }
+    Classifier C;
+    Options &o = C.opt;
+    for (int i = 1; i < argc; i++) {
+        const std::string val(argv[i]);
+        auto need = [&](const char *msg) { if (++i >= argc) die(msg); return argv[i]; };
+        if (val == "-k") { o.k = (size_t)atoi(need("Please specify the k-mer length!")); if (o.k <= 1 || o.k > MAXK) die("The k-mer length should be in [2," + std::to_string(MAXK) + "]."); continue; }
+        if (val == "-t") { o.minT = (unsigned)atoi(need("Please specify the minimum frequency (targets)!")); if (o.minT >= 65536) die("The min k-mer frequency should be in [0,65535]."); continue; }
+        if (val == "-n") { o.cpu = (size_t)atoi(need("Please specify the number of threads!")); if (o.batches < o.cpu) o.batches = o.cpu; if (o.cpu < 1) die("The number of threads should be higher than 0."); continue; }
+        if (val == "--tsk") { o.tsk = true; continue; }
+        if (val == "--extended") { o.ext = true; continue; }
+        if (val == "-T") { o.targets = need("Please specify the targets!"); if (!file_readable(o.targets)) die(std::string("Failed to find/read the file of the targets definition: ") + o.targets); continue; }
+        if (val == "-O") { o.objects = need("Please specify the objects!"); if (!file_readable(o.objects)) die(std::string("Failed to find/read the filename of objects: ") + o.objects); continue; }
+        if (val == "-P") {
+            if (i + 2 >= argc) die("Please specify the paired-end reads!");
+            o.objects = argv[++i]; o.objects2 = argv[++i];
+            if (!file_readable(o.objects)) die(std::string("Failed to find/read ") + o.objects);
+            if (!file_readable(o.objects2)) die(std::string("Failed to find/read ") + o.objects2);
+            continue;
+        }
+        if (val == "-D") { o.folder = need("Please specify the database directory!"); if (!file_readable(o.folder)) die(std::string("Failed to find/read the directory:  ") + o.folder); continue; }
+        if (val == "-R") { o.results = need("Please specify where to store results!"); continue; }
+        if (val == "-g") { o.gap = (size_t)atoi(need("Please specify a gap value!")); if (o.gap < 4) die("The gap value should be >= 4."); continue; }
+        if (val == "-s") { o.sfactor = (unsigned)atoi(need("Please specify a sampling factor value!")); if (o.sfactor < 2 || o.sfactor > SFACTORMAX) die("The sampling factor value should be in the interval [2," + std::to_string(SFACTORMAX) + "]."); continue; }
+        if (val == "-b") { o.batches = (size_t)atoi(need("Please specify the number of batches!")); if (o.batches < o.cpu) die("The number of batches should be higher than the number of threads."); continue; }
+        if (val == "-d") { o.devices = (size_t)atoi(need("Please specify the number of devices to use!")); if (o.devices < 1) die("The number of devices should be higher than 0."); continue; }
+        if (val == "--verbose") { o.verbose = true; continue; }
+        if (val == "--dump-batches") { o.dump = need("--dump-batches needs a file"); continue; }
+        die("Failed to recognize option: " + val);
+    }
+    // reference src/main.cc:214-228
+    if (HTSIZE == LHTSIZE) { if (o.gap == 0) o.gap = 4; o.k = 27; o.sfactor = 1; }
+    else o.gap = 0;
+    if (!o.targets || !o.folder || !o.objects || !o.results) {
+        std::cerr << "Failed to run " << argv[0] << ": at least four  parameters are necessary"
+                  << ": file of targets, directory of database, file of objects, file for results." << std::endl;
+        print_usage();
+        return 1;
+    }
+    C.folder = o.folder;
+    if (C.folder.back() != '/') C.folder.push_back('/');
+    C.key_bytes = key_bytes_for((unsigned)o.k);
+    if (C.key_bytes == 8) die("k = 32 needs 8-byte keys: not supported by this build yet (k <= 31).", -1);
+#ifdef _OPENMP
+    omp_set_num_threads((int)o.cpu);
+#endif
+    std::string err;
+    if (!read_targets(o.targets, C.T, err)) die(err, -1);
+    C.build_if_missing();
+    C.open_devices();
+    C.load();
+    C.run();
+    for (auto *c : C.ctx) mc_close(c);
+    return 0;
+}

@@ -1,0 +1,175 @@
+// reads.hpp -- FASTA/FASTQ indexing, the 2-bit read packer and mate pairing.
+//
+// Output format is the batch format the GPU kernels consume, unchanged from the
+// reference (src/CuCLARK_hh.hh:1615-1715):
+//   reads_ptr[i]  = u32 offset of read i in containers[]     (reads_ptr[n] = total)
+//   a read        = its parts, one after the other; a part is a maximal run of
+//                   ACGTU (either case, '\n' ignored) at least k long:
+//                   [length][ceil(length/8) containers], 8 bases per u16, first base
+//                   in the high bits, last container left-aligned.
+//   reads shorter than k, and parts shorter than k, contribute nothing.
+#pragma once
+
+#include "common.hpp"
+
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+namespace host {
+
+struct ReadIndex {
+    std::vector<uint64_t> name_s, name_e;   // object name = bytes [name_s, name_e)
+    std::vector<uint64_t> spos, epos;       // sequence bytes [spos, epos) (may span lines)
+    std::vector<uint64_t> len;              // bases, newlines not counted
+    size_t size() const { return len.size(); }
+};
+
+inline bool is_sep(uint8_t c) { return c == ' ' || c == '\t' || c == '\n'; }
+
+// One pass over the file image.  Record rules as in the reference
+// (src/CuCLARK_hh.hh:1340-1404 FASTA, :1476-1533 FASTQ): the name ends at the first
+// space/tab/newline; a FASTA sequence runs to the next '>' ; FASTQ records are 4 lines.
+inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &err)
+{
+    if (nb == 0) { err = "empty file"; return false; }
+    if (t[0] == '>') {
+        size_t i = 1;
+        while (true) {
+            R.name_s.push_back(i);
+            while (i < nb && !is_sep(t[++i])) {}      // as the reference: the first byte is never a separator
+            R.name_e.push_back(i);
+            while (i < nb && t[i] != '\n') i++;
+            if (i < nb) i++;
+            const size_t s = i;
+            size_t e = i, lines = 0;
+            while (i < nb && t[i] != '>') {
+                const void *p = std::memchr(t + i, '\n', nb - i);
+                const size_t j = p ? (size_t)((const uint8_t *)p - t) : nb;
+                lines++;
+                e = j;
+                i = j < nb ? j + 1 : nb;
+            }
+            R.spos.push_back(s);
+            R.epos.push_back(e);
+            // bytes minus the newlines inside (the last line's newline is outside [s, e))
+            R.len.push_back(e > s ? e - s - (lines ? lines - 1 : 0) : 0);
+            if (i >= nb) break;
+            i++;   // past '>'
+        }
+        return true;
+    }
+    if (t[0] == '@') {
+        size_t i = 1;
+        while (true) {
+            R.name_s.push_back(i);
+            while (i < nb && !is_sep(t[++i])) {}      // as the reference: the first byte is never a separator
+            R.name_e.push_back(i);
+            while (i < nb && t[i] != '\n') i++;
+            if (i < nb) i++;
+            const size_t s = i;
+            const void *p = i < nb ? std::memchr(t + i, '\n', nb - i) : nullptr;
+            const size_t e = p ? (size_t)((const uint8_t *)p - t) : nb;
+            R.spos.push_back(s);
+            R.epos.push_back(e);
+            R.len.push_back(e - s);
+            i = e < nb ? e + 1 : nb;
+            for (int l = 0; l < 2; l++) {          // '+' line and quality line
+                const void *q = i < nb ? std::memchr(t + i, '\n', nb - i) : nullptr;
+                i = q ? (size_t)((const uint8_t *)q - t) + 1 : nb;
+            }
+            if (i + 1 >= nb) break;
+            i++;   // past '@'
+        }
+        return true;
+    }
+    err = "Failed to recognize the format of the file.";
+    return false;
+}
+
+// Worst-case number of containers for reads [r0, r1): one length slot per part (a part
+// needs >= k bases) plus one container per 8 bases, rounded up per part.
+inline size_t container_bound(const ReadIndex &R, size_t r0, size_t r1, unsigned k)
+{
+    size_t c = 0;
+    for (size_t i = r0; i < r1; i++) {
+        const size_t L = R.len[i];
+        if (L < k) continue;
+        const size_t parts = L / k;
+        c += L / 8 + 2 * parts + 2;
+    }
+    return c + 8;
+}
+
+// Pack reads [r0, r1) of the file image.  Returns the number of containers written.
+inline size_t pack_reads(const uint8_t *t, const ReadIndex &R, size_t r0, size_t r1, unsigned k,
+                         uint32_t *ptr, uint16_t *con)
+{
+    const auto &ct = codes();
+    size_t count = 0;
+    for (size_t ir = r0; ir < r1; ir++) {
+        ptr[ir - r0] = (uint32_t)count;
+        if (R.len[ir] < k) continue;
+        size_t i = R.spos[ir];
+        const size_t e = R.epos[ir];
+        while (i < e) {
+            // skip to the start of a run
+            while (i < e && ct.r[t[i]] < 0) i++;
+            if (i >= e) break;
+            const size_t slot = count++;      // length slot of this part
+            uint32_t plen = 0, cur = 0;
+            uint16_t w = 0;
+            while (i < e) {
+                const int code = ct.r[t[i]];
+                if (code < 0) {
+                    if (t[i] == '\n') { i++; continue; }
+                    break;
+                }
+                w = (uint16_t)((w << 2) | code);
+                i++;
+                if (++cur == 8) { con[count++] = w; plen += 8; cur = 0; w = 0; }
+            }
+            if (cur) { con[count++] = (uint16_t)(w << (2 * (8 - cur))); plen += cur; }
+            if (plen < k) count = slot;           // too short: drop the part
+            else con[slot] = (uint16_t)plen;      // a part is at most 65535 bases (u16 slot)
+        }
+    }
+    ptr[r1 - r0] = (uint32_t)count;
+    return count;
+}
+
+// FASTQ mates -> FASTA records ">id\nR1NR2" (reference mergePairedFiles, src/file.cc:205-268;
+// ids must match after cutting at ' ', '/', '\t', '@').
+inline bool merge_paired(const char *f1, const char *f2, const char *out, std::string &err)
+{
+    std::ifstream a(f1), b(f2);
+    if (!a || !b) { err = "Failed to open paired files"; return false; }
+    std::ofstream o(out, std::ios::binary);
+    std::string l1, l2;
+    auto id_of = [](const std::string &l) {
+        size_t s = 0;
+        while (s < l.size() && (l[s] == ' ' || l[s] == '/' || l[s] == '\t' || l[s] == '@')) s++;
+        size_t e = s;
+        while (e < l.size() && l[e] != ' ' && l[e] != '/' && l[e] != '\t' && l[e] != '@') e++;
+        return l.substr(s, e - s);
+    };
+    bool first = true;
+    while (std::getline(a, l1) && std::getline(b, l2)) {
+        if (first) {
+            first = false;
+            if (l1.empty() || l2.empty() || l1[0] != l2[0]) { err = "Error: the files have different format!"; return false; }
+            if (l1[0] != '@') { err = "Error: paired-end reads must be FASTQ files!"; return false; }
+        }
+        if (l1.empty() || l2.empty() || l1[0] != '@' || l2[0] != '@') continue;
+        if (id_of(l1) != id_of(l2)) { err = "Error: read id does not match between files!"; return false; }
+        o << ">" << id_of(l1) << "\n";
+        if (!(std::getline(a, l1) && std::getline(b, l2))) { err = "Error: Found read without sequence"; return false; }
+        o << l1 << "N" << l2 << "\n";
+        std::getline(a, l1); std::getline(b, l2);     // '+'
+        std::getline(a, l1); std::getline(b, l2);     // quality
+    }
+    return true;
+}
+
+} // namespace host

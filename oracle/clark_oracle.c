@@ -564,6 +564,15 @@ void orc_result_rows(const uint16_t *rows, size_t row_len, size_t n_reads, uint1
     }
 }
 
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -137,6 +137,7 @@ void orc_classify_batch(const orc_db *db, int k, uint32_t num_targets, uint32_t 
                         uint16_t *out5, uint64_t *n_overflow);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 /* ---- CSV line ------------------------------------------------------------ */
 

@@ -64,6 +64,8 @@ def lib():
         L.orc_classify_batch.restype = None
         L.orc_classify_batch.argtypes = [vp, C.c_int, u32, u32, vp, vp, C.c_size_t, vp, u64p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.restype = None
+        L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_csv_line.restype = C.c_int
         L.orc_csv_line.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp, u64, C.c_int, C.c_char_p]
         _lib = L
@@ -227,3 +229,19 @@ def csv_line(name, res5, norm_len, k, assignment):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))

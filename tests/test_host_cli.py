@@ -1,0 +1,188 @@
+"""The C++ host driver (bin/cuCLARK, bin/cuCLARK-l): command line, database build from
+targets.txt (BASELINE config 1 plumbing, CPU), packer, CSV -- against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from jn_cuclark_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+def _build():
+    if not (os.path.exists(os.path.join(BIN, "cuCLARK")) and os.path.exists(os.path.join(BIN, "cuCLARK-l"))):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def _write_targets(tmp_path, genomes, labels, n_mask=True):
+    lines = []
+    for i, g in enumerate(genomes):
+        s = bytearray(synth.codes_to_ascii(g))
+        if n_mask and i == 0:
+            s[500] = ord("N")                 # an ambiguous base resets the k-mer window
+        p = tmp_path / ("genome%d.fa" % i)
+        p.write_bytes(synth.fasta_text([b"seq%d some description" % i], [bytes(s)], width=70))
+        lines.append("%s\t%s\n" % (p, labels[i]))
+    t = tmp_path / "targets.txt"
+    t.write_text("".join(lines))
+    return str(t)
+
+
+def _expected_db(genomes, labels, k, light, gap=4, n_mask=True):
+    """numpy model of the builder: overlapping windows (full) or every gap-th of the
+    consecutive non-overlapping windows (light, reference CuCLARK_hh.hh:707-760)."""
+    uniq = []
+    for l in labels:
+        if l not in uniq:
+            uniq.append(l)
+    km, tg = [], []
+    for i, g in enumerate(genomes):
+        runs = [g]
+        if n_mask and i == 0:
+            runs = [g[:500], g[501:]]
+        it = 0
+        for r in runs:
+            if not light:
+                x = synth.kmers_of(r, k)
+            else:
+                starts = np.arange(0, r.size - k + 1, k)
+                x = synth.kmers_of(r, k)[starts]
+                keep = (it + np.arange(starts.size)) % gap == 0
+                it += starts.size
+                x = x[keep]
+            km.append(x)
+            tg.append(np.full(x.size, uniq.index(labels[i]), dtype=np.uint16))
+    return synth.discriminative(np.concatenate(km), np.concatenate(tg), k), uniq
+
+
+def _run(exe, args, check_gpu=True):
+    return subprocess.run([os.path.join(BIN, exe)] + args, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_database_build_from_targets_matches_model(oracle, tmp_path, variant):
+    """-T targets.txt -> db_central_k*_t*_s*_m*.tsk.{sz,ky,lb}; runs on the CPU, before
+    any device is opened (on a machine without GPU the run then stops with an error)."""
+    _build()
+    light = variant == "light"
+    k = 27 if light else 31
+    ht = 57777779 if light else 1610612741
+    genomes = synth.toy_genomes(3, 4000, seed=41, shared=600)
+    labels = ["562", "1280", "562"]            # two files share one label (one target)
+    targets = _write_targets(tmp_path, genomes, labels)
+    reads = tmp_path / "reads.fa"
+    reads.write_bytes(synth.fasta_text([b"r0"], [synth.codes_to_ascii(genomes[0][:150])]))
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    exe = "cuCLARK-l" if light else "cuCLARK"
+    r = _run(exe, ["-k", str(k), "-T", targets, "-D", str(dbdir), "-O", str(reads), "-R", str(tmp_path / "out")])
+    name = "db_central_k%d_t2_s%d_m0%s.tsk" % (k, ht, "_light_4" if light else "")
+    base = str(dbdir / name)
+    assert os.path.exists(base + ".sz"), r.stderr
+    (canon, lab), uniq = _expected_db(genomes, labels, k, light)
+    order = np.lexsort((canon // np.uint64(ht), canon % np.uint64(ht)))
+    canon, lab = canon[order], lab[order]
+    ky = np.fromfile(base + ".ky", dtype=np.uint32)
+    lb = np.fromfile(base + ".lb", dtype=np.uint16)
+    assert os.path.getsize(base + ".sz") == ht
+    assert np.array_equal(ky, (canon // np.uint64(ht)).astype(np.uint32))
+    assert np.array_equal(lb, lab)
+    sz = np.fromfile(base + ".sz", dtype=np.uint8)
+    nz, cnt = np.unique((canon % np.uint64(ht)).astype(np.int64), return_counts=True)
+    assert np.array_equal(np.flatnonzero(sz), nz) and np.array_equal(sz[nz], cnt.astype(np.uint8))
+    os.remove(base + ".sz")
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "No HIP devices" in r.stderr      # no silent CPU fallback
+
+
+def test_cli_errors_match_reference_messages(tmp_path):
+    _build()
+    r = _run("cuCLARK", ["-k", "40", "-T", "x", "-D", "y", "-O", "z", "-R", "w"])
+    assert r.returncode == 1 and "The k-mer length should be in [2,32]." in r.stderr
+    r = _run("cuCLARK", ["-k", "31", "-T", str(tmp_path / "missing"), "-D", "y", "-O", "z", "-R", "w"])
+    assert r.returncode == 1 and "Failed to find/read the file of the targets definition" in r.stderr
+    r = _run("cuCLARK", ["--version"])
+    assert r.returncode == 0 and "Version: 1.1" in r.stdout
+    r = _run("cuCLARK", ["-k", "31", "--bogus", "1", "2", "3", "4"])
+    assert r.returncode == 1 and "Failed to recognize option: --bogus" in r.stderr
+
+
+def _expected_csv(oracle, text, k, ht, base, names, paired=False, extended=False, maxhits=23):
+    ns, ne, sp, ep, ln = oracle.index_reads(text)
+    rp, con = oracle.pack_reads(text, sp, ep, ln, k)
+    odb = oracle.OracleDB.load(base, ht, 4)
+    rows, _ = odb.query_rows(k, rp, con, maxhits)
+    res = oracle.result_rows(rows)
+    out = ["Object_ID" + ("," + ",".join(names[1:]) if extended else "") + ",Gamma,Assignment,Score,Confidence\n"]
+    for i in range(ln.size):
+        line = oracle.csv_line(text[int(ns[i]):int(ne[i])], res[i], int(ln[i]) - (1 if paired else 0), k, names[int(res[i, 1])])
+        if extended:
+            dense = np.zeros(len(names) - 1, dtype=np.int64)
+            for j in range(int(rows[i, 0])):
+                dense[int(rows[i, 1 + 2 * j])] = int(rows[i, 2 + 2 * j])
+            nm, rest = line.split(",", 1)
+            line = nm + "".join(",%d" % v for v in dense) + "," + rest
+        out.append(line)
+    return "".join(out), (rp, con)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fasta", "fastq_batches", "paired", "extended"])
+def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    _build()
+    k, ht = 27, 57777779
+    genomes = synth.toy_genomes(4, 5000, seed=51, shared=500)
+    labels = ["Ecoli", "Saureus", "Bsub", "Paer"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    names, seqs = mixed_fasta(genomes, k, seed=13, n=1500)
+    args = ["-T", targets, "-D", str(dbdir), "-R", str(tmp_path / "res"), "--dump-batches", str(tmp_path / "dump.bin")]
+    paired = mode == "paired"
+    if paired:
+        m1 = [s[:100].replace(b"\n", b"") for s in seqs]
+        m2 = [s[50:150] for s in seqs]
+        nm = [n.split(b" ")[0] for n in names]
+        f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
+        f1.write_bytes(synth.fastq_text([n + b"/1" for n in nm], m1))
+        f2.write_bytes(synth.fastq_text([n + b"/2" for n in nm], m2))
+        args += ["-P", str(f1), str(f2)]
+        text = synth.fasta_text(nm, [a + b"N" + b for a, b in zip(m1, m2)])
+    elif mode == "fastq_batches":
+        text = synth.fastq_text(names, seqs)
+        p = tmp_path / "reads.fq"
+        p.write_bytes(text)
+        args += ["-O", str(p), "-n", "4", "-b", "7"]
+    else:
+        text = synth.fasta_text(names, seqs, width=60)
+        p = tmp_path / "reads.fa"
+        p.write_bytes(text)
+        args += ["-O", str(p)] + (["--extended"] if mode == "extended" else [])
+    r = _run("cuCLARK-l", args)
+    assert r.returncode == 0, r.stderr
+    base = str(dbdir / ("db_central_k27_t4_s%d_m0_light_4.tsk" % ht))
+    want, (rp, con) = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, paired=paired,
+                                    extended=mode == "extended")
+    got = open(str(tmp_path / "res.csv")).read()
+    assert got == want
+    # the packed batches equal the oracle's restatement of the reference packer
+    raw = open(str(tmp_path / "dump.bin"), "rb").read()
+    off, ptrs, cons = 0, [], []
+    while off < len(raw):
+        n, c = np.frombuffer(raw, dtype=np.uint64, count=2, offset=off)
+        off += 16
+        ptrs.append(np.frombuffer(raw, dtype=np.uint32, count=int(n) + 1, offset=off)); off += 4 * (int(n) + 1)
+        cons.append(np.frombuffer(raw, dtype=np.uint16, count=int(c), offset=off)); off += 2 * int(c)
+    assert np.array_equal(np.concatenate(cons), con)
+    starts = np.concatenate([[0], np.cumsum([c.size for c in cons])[:-1]])
+    flat = np.concatenate([p[:-1].astype(np.int64) + s for p, s in zip(ptrs, starts)] + [[con.size]])
+    assert np.array_equal(flat, rp.astype(np.int64))
+    assert "Done in" in r.stderr and "reads/min" in r.stderr
