@@ -1,0 +1,189 @@
+// CuClarkDB_mc.cc -- drop-in replacement for the reference's src/CuClarkDB.cu.
+//
+// Implements the member functions of `template <typename HKMERr> class CuClarkDB`
+// exactly as declared in the reference's src/CuClarkDB.cuh:39-153, on top of the C ABI
+// of libmcclark.so (include/mc_api.h).  A maintainer builds cuCLARK / cuCLARK-l with
+// this file in place of CuClarkDB.cu; nothing else in the
+// reference's host code (src/main.cc, src/CuCLARK_hh.hh) changes.
+//
+// The class declaration stays the reference's, so this file cannot add members: the
+// per-object state lives in a side table keyed by `this`.  No algorithm lives here --
+// only the mapping between the two interfaces:
+//   ctor            -> mc_open          (HTSIZE / MAXHITS from the reference's parameters.hh)
+//   read            -> mc_load_db       (false when the files are missing, as the reference)
+//   malloc          -> mc_alloc_batches + mc_batch_buffers; the two whole-file result tables
+//                      the host indexes by global read number are plain pinned-size host arrays
+//   readyBatch      -> remembered sizes
+//   queryBatch      -> mc_submit        (always returns true: the table is resident, one cycle)
+//   swapDbParts     -> one cycle, then false (reference :775-815 cycles DB parts)
+//   waitForBatch    -> mc_wait + copy of the batch's rows into the whole-file tables
+//   sync / freeBatchMemory -> mc_sync / mc_free_batches
+#include "CuClarkDB.cuh"          // the reference's header, unchanged
+#include "mc_api.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <mutex>
+
+namespace {
+
+struct State {
+    mc_ctx *ctx = nullptr;
+    int cycles_to_do = 1;
+    bool extended = false;
+    size_t row_len = 0, final_len = 0;
+    RESULTS *full = nullptr, *final_ = nullptr;
+    std::vector<ITYPE> index;             // first global read of every batch
+    std::vector<size_t> n_reads, n_con;
+};
+
+std::mutex g_mu;
+std::map<const void *, State> g_state;
+
+State &st(const void *self)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_state[self];
+}
+
+void check(int rc, const char *what)
+{
+    if (rc != MC_OK) {
+        std::cerr << what << ": " << mc_last_error() << std::endl;   // reference CUERR: print + exit(1)
+        exit(1);
+    }
+}
+
+} // namespace
+
+template <typename HKMERr>
+CuClarkDB<HKMERr>::CuClarkDB(const size_t _numDevices, const uint8_t _k, const size_t _numBatches,
+                             const size_t _numTargets, bool _verbose)
+    : m_k(_k), m_numTargets(_numTargets), m_numBatches(_numBatches), m_verbose(_verbose), d_resultsFinal(nullptr)
+{
+    int n = 0;
+    if (mc_device_count(&n) != MC_OK || n < 1) { std::cerr << "No HIP devices found. Abort.\n"; exit(1); }
+    if ((size_t)n < _numDevices) { std::cerr << _numDevices << " devices requested. Insufficient devices found. Abort.\n"; exit(1); }
+    m_numDevices = 1;                      // one context; more GPUs = more processes
+    m_dbParts = 1; m_dbPartsPerDevice = 1; m_cyclesPerDevice = 1; m_cyclesToDo = 1;
+    State &s = st(this);
+    check(mc_open(&s.ctx, 0, _k, (uint64_t)HTSIZE, (uint32_t)_numTargets, (uint32_t)MAXHITS), "mc_open");
+}
+
+template <typename HKMERr>
+CuClarkDB<HKMERr>::~CuClarkDB()
+{
+    State &s = st(this);
+    mc_close(s.ctx);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_state.erase(this);
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::read(const char *_filename, size_t &_fileSize, size_t &_dbParts, const ITYPE &_modCollision)
+{
+    State &s = st(this);
+    const int rc = mc_load_db(s.ctx, _filename, (int)sizeof(HKMERr), _modCollision, 0, 0);
+    if (rc == MC_EIO) { std::cerr << mc_last_error() << std::endl; return false; }
+    check(rc, "mc_load_db");
+    mc_db_info info;
+    check(mc_get_db_info(s.ctx, &info), "mc_get_db_info");
+    _fileSize = info.device_bytes;
+    _dbParts = 1;
+    s.cycles_to_do = 1;
+    std::cerr << (m_verbose ? "DB loaded in HBM.\n" : "CuCLARK initialized.\n");
+    return true;
+}
+
+template <typename HKMERr>
+size_t CuClarkDB<HKMERr>::malloc(size_t _numReads, size_t _maxReads, size_t _maxReadsInContainers,
+                                 std::vector<ITYPE> &_indexBatches, RESULTS *&_fullResults, size_t _resultRowSize,
+                                 RESULTS *&_finalResults, size_t _finalResultsRowSize, bool _isExtended,
+                                 std::vector<uint32_t *> &_readsPointer, std::vector<CONTAINER *> &_readsInCon)
+{
+    State &s = st(this);
+    s.extended = _isExtended;
+    s.row_len = _resultRowSize;
+    s.final_len = _finalResultsRowSize;
+    s.index = _indexBatches;
+    s.n_reads.assign(m_numBatches, 0);
+    s.n_con.assign(m_numBatches, 0);
+    check(mc_alloc_batches(s.ctx, (uint32_t)m_numBatches, _maxReads ? _maxReads : 1, _maxReadsInContainers,
+                           _isExtended ? 1 : 0), "mc_alloc_batches");
+    _readsPointer.resize(m_numBatches);
+    _readsInCon.resize(m_numBatches);
+    for (size_t b = 0; b < m_numBatches; b++)
+        check(mc_batch_buffers(s.ctx, (uint32_t)b, &_readsPointer[b], &_readsInCon[b], nullptr, nullptr), "mc_batch_buffers");
+    _fullResults = nullptr;
+    if (_isExtended) _fullResults = (RESULTS *)std::calloc(_numReads * _resultRowSize + 1, sizeof(RESULTS));
+    _finalResults = (RESULTS *)std::calloc(_numReads * _finalResultsRowSize + 1, sizeof(RESULTS));
+    s.full = _fullResults;
+    s.final_ = _finalResults;
+    return (_maxReads + 1) * sizeof(uint32_t) + _maxReadsInContainers * sizeof(CONTAINER);
+}
+
+template <typename HKMERr>
+void CuClarkDB<HKMERr>::freeBatchMemory()
+{
+    State &s = st(this);
+    mc_free_batches(s.ctx);
+    std::free(s.full); std::free(s.final_);
+    s.full = s.final_ = nullptr;
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::sync()
+{
+    check(mc_sync(st(this).ctx), "mc_sync");
+    return true;
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::readyBatch(const size_t _batchId, const size_t _numReads, const size_t _containerCount)
+{
+    State &s = st(this);
+    s.n_reads[_batchId] = _numReads;
+    s.n_con[_batchId] = _containerCount;
+    return true;
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::queryBatch(const size_t _batchId, const bool _isExtended, const bool)
+{
+    State &s = st(this);
+    check(mc_submit(s.ctx, (uint32_t)_batchId, s.n_reads[_batchId], s.n_con[_batchId],
+                    MC_F_FINAL | (_isExtended ? MC_F_ROWS : 0)), "mc_submit");
+    return true;
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::swapDbParts()
+{
+    State &s = st(this);
+    if (s.cycles_to_do == 0) { s.cycles_to_do = 1; return false; }
+    s.cycles_to_do--;
+    return true;
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::waitForBatch(size_t batchId)
+{
+    State &s = st(this);
+    check(mc_wait(s.ctx, (uint32_t)batchId), "mc_wait");
+    uint16_t *fin = nullptr, *rows = nullptr;
+    check(mc_batch_buffers(s.ctx, (uint32_t)batchId, nullptr, nullptr, &fin, &rows), "mc_batch_buffers");
+    const size_t n = s.n_reads[batchId], at = s.index[batchId];
+    std::memcpy(s.final_ + at * s.final_len, fin, n * s.final_len * sizeof(RESULTS));
+    if (s.extended) std::memcpy(s.full + at * s.row_len, rows, n * s.row_len * sizeof(RESULTS));
+    return true;
+}
+
+template <typename HKMERr>
+bool CuClarkDB<HKMERr>::checkBatch(size_t) { return true; }
+
+template class CuClarkDB<uint16_t>;
+template class CuClarkDB<uint32_t>;
+template class CuClarkDB<uint64_t>;

@@ -1,0 +1,92 @@
+"""GPU suite: the REFERENCE's own host driver (src/main.cc + src/CuCLARK_hh.hh: targets
+parser, database builder, FASTA/FASTQ indexer, read packer, CSV writer), linked against
+our HIP backend through integration/CuClarkDB_mc.cc (oracle/_ref/ref_host_mc_light, built
+by `make -C oracle ref_host` where /root/reference exists), next to our own host driver
+bin/cuCLARK-l on the same inputs.  Database files and CSV must be byte-identical.
+
+This pins our host side (builder, indexer, packer, CSV formatting) against the reference's
+real code, and shows the C ABI is a working drop-in for src/CuClarkDB.cu."""
+import filecmp
+import os
+import subprocess
+import sys
+
+import pytest
+
+from jn_cuclark_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_host_mc_light")
+OURS = os.path.join(ROOT, "bin", "cuCLARK-l")
+
+
+def _targets(tmp_path, genomes, labels):
+    lines = []
+    for i, g in enumerate(genomes):
+        s = bytearray(synth.codes_to_ascii(g))
+        s[777] = ord("N")
+        s[2000:2010] = b"nnnnnRYKMS"
+        p = tmp_path / ("genome%d.fa" % i)
+        p.write_bytes(synth.fasta_text([b"contig%d x" % i, b"contig%d_b" % i], [bytes(s[:3000]), bytes(s[3000:])], width=80))
+        lines.append("%s\t%s\n" % (p, labels[i]))
+    t = tmp_path / "targets.txt"
+    t.write_text("".join(lines))
+    return str(t)
+
+
+@pytest.mark.parametrize("mode", ["fasta_multiline", "fastq_3batches", "paired", "extended"])
+def test_reference_host_and_our_host_agree_byte_for_byte(tmp_path, mode):
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/ref_host_mc_light not built (needs /root/reference at build time)")
+    if not os.path.exists(OURS):
+        import __graft_entry__
+        __graft_entry__.build()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    k = 27
+    genomes = synth.toy_genomes(5, 6000, seed=61, shared=700)
+    labels = ["Ecoli", "Saureus", "Bsub", "Ecoli", "Paer"]
+    targets = _targets(tmp_path, genomes, labels)
+    names, seqs = mixed_fasta(genomes, k, seed=17, n=1200)
+    names = [n + b" trailing words" for n in names]
+    extra = []
+    if mode == "paired":
+        nm = [n.split(b" ")[0] for n in names]
+        m1 = [s[:100].replace(b"\n", b"") for s in seqs]
+        m2 = [s[40:150] for s in seqs]
+        f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
+        f1.write_bytes(synth.fastq_text([n + b"/1" for n in nm], m1))
+        f2.write_bytes(synth.fastq_text([n + b"/2" for n in nm], m2))
+        inp = ["-P", str(f1), str(f2)]
+    elif mode == "fastq_3batches":
+        p = tmp_path / "reads.fq"
+        p.write_bytes(synth.fastq_text(names, seqs))
+        inp = ["-O", str(p)]
+        extra = ["-b", "3"]
+    else:
+        p = tmp_path / "reads.fa"
+        p.write_bytes(synth.fasta_text(names, seqs, width=50))
+        inp = ["-O", str(p)]
+        if mode == "extended":
+            extra = ["--extended"]
+    outs = {}
+    for tag, exe in (("ref", REF), ("ours", OURS)):
+        d = tmp_path / ("db_" + tag)
+        d.mkdir()
+        r = subprocess.run([exe, "-T", targets, "-D", str(d)] + inp + ["-R", str(tmp_path / ("res_" + tag))] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        outs[tag] = d
+    name = "db_central_k27_t4_s57777779_m0_light_4.tsk"
+    for ext in (".sz", ".ky", ".lb"):
+        a, b = str(outs["ref"] / (name + ext)), str(outs["ours"] / (name + ext))
+        assert os.path.getsize(a) > 0
+        assert filecmp.cmp(a, b, shallow=False), ext
+    ref_csv = open(str(tmp_path / "res_ref.csv")).read()
+    our_csv = open(str(tmp_path / "res_ours.csv")).read()
+    assert ref_csv.count("\n") == 1201
+    assert our_csv == ref_csv
+    assigned = sum(1 for ln in ref_csv.split("\n")[1:-1] if ",NA," not in ln)
+    assert assigned > 500
