@@ -220,7 +220,7 @@ def main():
             if not args.no_cpu_baseline:
                 cores = pyoracle.host_cores()
                 pyoracle.set_num_threads(cores)
-                m = args.cpu_sample or 100000 * cores
+                m = args.cpu_sample or 500000 * cores
                 m = min(m, n_reads // 2)
                 # half planted + half random, like the full batch
                 p, c1 = sample(0, m // 2)
