@@ -65,11 +65,18 @@ def main():
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
+    # multi-rank control flow on a one-GPU box (ranks then share the card)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from jn_cuclark_amd import CuClarkDB, synth_gpu
 
@@ -87,7 +94,7 @@ def main():
     d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, k, ht, args.targets, args.lam, genomes=genomes,
                                                 shard=shard if shard_mode else None)
     n_keys = int(d_keys.numel())
-    db = CuClarkDB(k=k, numBatches=1, numTargets=args.targets, device=local_rank, htsize=ht, maxhits=MAXHITS)
+    db = CuClarkDB(k=k, numBatches=1, numTargets=args.targets, device=dev_index, htsize=ht, maxhits=MAXHITS)
     db.read_device(d_sz, d_keys, d_labels, shard=shard)
     info = db.db_info()
     torch.cuda.synchronize()
@@ -137,7 +144,7 @@ def main():
     kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kern_ms_avg = sum(kern_ms) / len(kern_ms)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

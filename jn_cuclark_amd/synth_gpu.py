@@ -123,7 +123,8 @@ def bucket_host(seed, k, htsize, n_targets, lam, bucket):
     return keys[:cnt.value].copy(), labs[:cnt.value].copy()
 
 
-def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, chunk=1 << 20):
+def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, chunk=1 << 20,
+               return_truth=False):
     """n_reads packed reads of `length` bases: the first planted_frac are windows of the
     genomes with substitutions, the rest uniform random.  Returns (reads_ptr int32[n+1],
     containers int16[n*(1+ceil(L/8))]) in the reference batch format
@@ -138,6 +139,7 @@ def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, 
     n_planted = int(n_reads * planted_frac)
     ar = torch.arange(length, device=device, dtype=torch.int64)[None, :]
     sh = (14 - 2 * torch.arange(8, device=device, dtype=torch.int32))[None, None, :]
+    truth = []
     for s in range(0, n_reads, chunk):
         e = min(n_reads, s + chunk)
         m = e - s
@@ -145,6 +147,7 @@ def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, 
         codes = torch.randint(0, 4, (m, length), dtype=torch.uint8, device=device, generator=g)
         if n_pl:
             gi = torch.randint(0, T, (n_pl,), device=device, generator=g)
+            truth.append(gi)
             pos = torch.randint(0, G - length + 1, (n_pl,), device=device, generator=g)
             win = flat[(gi * G + pos)[:, None] + ar]
             mut = torch.rand((n_pl, length), device=device, generator=g) < sub_rate
@@ -158,4 +161,6 @@ def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, 
     if n_reads * (nc + 1) >= 2 ** 32:
         raise ValueError("batch exceeds the 32-bit container offsets of the batch format")
     ptr = (torch.arange(n_reads + 1, device=device, dtype=torch.int64) * (nc + 1)).to(torch.int32)
+    if return_truth:      # source genome of every planted read (the first n_planted reads)
+        return ptr, out.reshape(-1), (torch.cat(truth) if truth else torch.zeros(0, dtype=torch.int64, device=device))
     return ptr, out.reshape(-1)
