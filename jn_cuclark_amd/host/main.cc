@@ -150,7 +150,10 @@ struct Classifier {
 
         ReadIndex R;
         std::string err;
-        if (!index_reads(map, nb, R, err)) { std::cerr << err << std::endl; std::exit(-1); }
+        auto now = []() { struct timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + tv.tv_usec / 1e6; };
+        const double ts0 = now();
+        if (!index_reads_parallel(map, nb, (int)opt.cpu, R, err)) { std::cerr << err << std::endl; std::exit(-1); }
+        const double ts1 = now();
         n_objects = R.size();
         const size_t nbatch = std::max<size_t>(1, std::min(opt.batches, n_objects));
         std::vector<size_t> first(nbatch + 1);
@@ -198,6 +201,7 @@ struct Classifier {
             std::fclose(dump);
         }
 
+        const double ts2 = now();
         // header (reference :1951-1967)
         std::fputs("Object_ID", fout);
         if (opt.ext) for (size_t t = 1; t < T.names.size(); t++) std::fprintf(fout, ",%s", T.names[t].c_str());
@@ -206,44 +210,67 @@ struct Classifier {
 
         const size_t row_len = 2 * (size_t)MAXHITS + 2;
         long nz_min = (long)T.names.size() - 1, nz_max = 0, nz_sum = 0;
-        std::string cells;
+        // a batch's lines are formatted in parallel slices (same printf conversions as the
+        // reference, :2115-2118) and written in read order
+        const int nfmt = (int)std::max<size_t>(1, opt.cpu);
+        std::vector<std::string> slice(nfmt);
+        std::vector<long> s_min(nfmt), s_max(nfmt), s_sum(nfmt);
         for (size_t b = 0; b < nbatch; b++) {
             mc_check(mc_wait(ctx[where[b].first], where[b].second), "mc_wait");
             uint16_t *fin, *rows;
             mc_batch_buffers(ctx[where[b].first], where[b].second, nullptr, nullptr, &fin, &rows);
-            for (size_t i = first[b]; i < first[b + 1]; i++) {
-                const uint16_t *r5 = fin + (i - first[b]) * MC_FINAL_ROW;
-                const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
-                char name[OBJECTNAMEMAX];
-                size_t nl = R.name_e[i] - R.name_s[i];
-                if (nl >= OBJECTNAMEMAX) nl = OBJECTNAMEMAX - 1;
-                std::memcpy(name, map + R.name_s[i], nl);
-                name[nl] = '\0';
-                const uint32_t norm = (uint32_t)(paired ? R.len[i] - NBN : R.len[i]);     // ITYPE objectNorm
-                const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
-                double delta = (double)(best + s_best);
-                delta = (delta < 0.001) ? 0 : ((double)best) / delta;
-                const char *assign = ibest < T.names.size() ? T.names[ibest].c_str() : "NA";
-                if (!opt.ext) {
-                    std::fprintf(fout, "%s,%g,%s,%u,%g\n", name, gamma, assign, best, delta);
-                } else {
-                    // all scores, zeros for the targets not hit (reference :2006-2026)
-                    const uint16_t *row = rows + (i - first[b]) * row_len;
-                    cells.clear();
-                    size_t w = 0;
-                    for (uint32_t h = 0; h < row[0]; h++) {
-                        const size_t t = row[1 + 2 * h];
-                        for (; w < t; w++) cells += ",0";
-                        cells += ","; cells += std::to_string(row[2 + 2 * h]);
-                        w++;
+            const size_t r0 = first[b], nr = first[b + 1] - first[b];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(nfmt)
+#endif
+            for (int sl = 0; sl < nfmt; sl++) {
+                std::string &out = slice[sl];
+                out.clear();
+                s_min[sl] = (long)T.names.size() - 1; s_max[sl] = 0; s_sum[sl] = 0;
+                char line[256];
+                std::string cells;
+                for (size_t i = r0 + nr * sl / nfmt; i < r0 + nr * (sl + 1) / nfmt; i++) {
+                    const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
+                    const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
+                    size_t nl = R.name_e[i] - R.name_s[i];
+                    if (nl >= OBJECTNAMEMAX) nl = OBJECTNAMEMAX - 1;
+                    out.append((const char *)map + R.name_s[i], nl);
+                    const uint32_t norm = (uint32_t)(paired ? R.len[i] - NBN : R.len[i]);     // ITYPE objectNorm
+                    const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
+                    double delta = (double)(best + s_best);
+                    delta = (delta < 0.001) ? 0 : ((double)best) / delta;
+                    const char *assign = ibest < T.names.size() ? T.names[ibest].c_str() : "NA";
+                    if (opt.ext) {
+                        // all scores, zeros for the targets not hit (reference :2006-2026)
+                        const uint16_t *row = rows + (i - r0) * row_len;
+                        cells.clear();
+                        size_t w = 0;
+                        for (uint32_t h = 0; h < row[0]; h++) {
+                            const size_t t = row[1 + 2 * h];
+                            for (; w < t; w++) cells += ",0";
+                            cells += ","; cells += std::to_string(row[2 + 2 * h]);
+                            w++;
+                        }
+                        for (; w < T.names.size() - 1; w++) cells += ",0";
+                        out += cells;
+                        s_max[sl] = std::max<long>(s_max[sl], row[0]); s_min[sl] = std::min<long>(s_min[sl], row[0]); s_sum[sl] += row[0];
                     }
-                    for (; w < T.names.size() - 1; w++) cells += ",0";
-                    std::fprintf(fout, "%s%s,%g,%s,%u,%g\n", name, cells.c_str(), gamma, assign, best, delta);
-                    nz_max = std::max<long>(nz_max, row[0]); nz_min = std::min<long>(nz_min, row[0]); nz_sum += row[0];
+                    const int m = std::snprintf(line, sizeof line, ",%g,", gamma);
+                    out.append(line, (size_t)m);
+                    out += assign;
+                    const int m2 = std::snprintf(line, sizeof line, ",%u,%g\n", best, delta);
+                    out.append(line, (size_t)m2);
                 }
+            }
+            for (int sl = 0; sl < nfmt; sl++) {
+                std::fwrite(slice[sl].data(), 1, slice[sl].size(), fout);
+                if (opt.ext && nr) { nz_max = std::max(nz_max, s_max[sl]); nz_min = std::min(nz_min, s_min[sl]); nz_sum += s_sum[sl]; }
             }
         }
         std::fclose(fout);
+        if (opt.verbose)
+            std::cerr << "timing: index " << ts1 - ts0 << " s, alloc+pack+submit " << ts2 - ts1 << " s, wait+format+write "
+                      << now() - ts2 << " s\n";
         std::cerr << "Done." << std::endl;
         if (opt.ext && n_objects)
             std::cerr << "MIN targets: " << nz_min << ", MAX targets: " << nz_max << ", AVG targets: "

@@ -88,6 +88,70 @@ inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &
     return false;
 }
 
+// Parallel front end of index_reads: the file is cut into `nthreads` byte ranges, every
+// range is moved forward to the next record start and indexed on its own thread, and
+// the pieces are concatenated.  Record starts are found without context:
+//   FASTA  a '>' that begins a line;
+//   FASTQ  a line starting with '@' whose second-next line starts with '+' (a quality
+//          line may start with '@', but then the line two below it is a sequence line).
+// The reference does the same cut per batch (src/CuCLARK_hh.hh:1345-1365, :1409-1471);
+// per-read results do not depend on where the cuts fall.
+inline size_t next_line(const uint8_t *t, size_t nb, size_t i)
+{
+    const void *p = i < nb ? std::memchr(t + i, '\n', nb - i) : nullptr;
+    return p ? (size_t)((const uint8_t *)p - t) + 1 : nb;
+}
+
+inline size_t record_start_at_or_after(const uint8_t *t, size_t nb, size_t pos, bool fastq)
+{
+    if (pos == 0) return 0;
+    size_t i = next_line(t, nb, pos - 1);          // first line start >= pos
+    while (i < nb) {
+        if (!fastq) { if (t[i] == '>') return i; }
+        else if (t[i] == '@') {
+            const size_t l2 = next_line(t, nb, next_line(t, nb, i));
+            if (l2 < nb && t[l2] == '+') return i;
+        }
+        i = next_line(t, nb, i);
+    }
+    return nb;
+}
+
+inline bool index_reads_parallel(const uint8_t *t, size_t nb, int nthreads, ReadIndex &R, std::string &err)
+{
+    if (nb == 0) { err = "empty file"; return false; }
+    if (t[0] != '>' && t[0] != '@') { err = "Failed to recognize the format of the file."; return false; }
+    const bool fastq = t[0] == '@';
+    if (nthreads < 1) nthreads = 1;
+    if (nb < (size_t)(1 << 20) || nthreads == 1) return index_reads(t, nb, R, err);
+    std::vector<size_t> cut(nthreads + 1);
+    for (int p = 0; p <= nthreads; p++) cut[p] = p == nthreads ? nb : record_start_at_or_after(t, nb, nb / nthreads * p, fastq);
+    std::vector<ReadIndex> part(nthreads);
+    std::vector<std::string> errs(nthreads);
+    std::vector<char> ok(nthreads, 1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+#endif
+    for (int p = 0; p < nthreads; p++) {
+        if (cut[p] >= cut[p + 1]) continue;
+        ok[p] = index_reads(t + cut[p], cut[p + 1] - cut[p], part[p], errs[p]);
+    }
+    size_t total = 0;
+    for (int p = 0; p < nthreads; p++) { if (!ok[p]) { err = errs[p]; return false; } total += part[p].size(); }
+    R.name_s.resize(total); R.name_e.resize(total); R.spos.resize(total); R.epos.resize(total); R.len.resize(total);
+    size_t at = 0;
+    for (int p = 0; p < nthreads; p++) {
+        const size_t n = part[p].size(), off = cut[p];
+        for (size_t i = 0; i < n; i++) {
+            R.name_s[at + i] = part[p].name_s[i] + off; R.name_e[at + i] = part[p].name_e[i] + off;
+            R.spos[at + i] = part[p].spos[i] + off;     R.epos[at + i] = part[p].epos[i] + off;
+            R.len[at + i] = part[p].len[i];
+        }
+        at += n;
+    }
+    return true;
+}
+
 // Worst-case number of containers for reads [r0, r1): one length slot per part (a part
 // needs >= k bases) plus one container per 8 bases, rounded up per part.
 inline size_t container_bound(const ReadIndex &R, size_t r0, size_t r1, unsigned k)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the host driver on a FASTQ file (run on the GPU box):
+generate n reads of 150 bp (half from toy genomes), build a light database through the
+driver itself, then time `bin/cuCLARK-l -O reads.fq` as the reference reports it
+(`Done in Xs (N reads/min, M reads)`, src/CuCLARK_hh.hh:1931-1939)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jn_cuclark_amd import synth  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    threads = sys.argv[2] if len(sys.argv) > 2 else "16"
+    work = sys.argv[3] if len(sys.argv) > 3 else "/tmp/e2e"
+    os.makedirs(work + "/db", exist_ok=True)
+    genomes = synth.toy_genomes(8, 200_000, seed=71)
+    tl = []
+    for i, g in enumerate(genomes):
+        p = "%s/g%d.fa" % (work, i)
+        open(p, "wb").write(synth.fasta_text([b"g%d" % i], [synth.codes_to_ascii(g)], width=80))
+        tl.append("%s\tT%d\n" % (p, i))
+    open(work + "/targets.txt", "w").write("".join(tl))
+    t0 = time.time()
+    rng = np.random.default_rng(5)
+    half = n // 2
+    gi = rng.integers(0, 8, half)
+    pos = rng.integers(0, 200_000 - 150, half)
+    allg = np.stack(genomes)
+    idx = pos[:, None] + np.arange(150)[None, :]
+    planted = allg[gi[:, None], idx]
+    mut = rng.random((half, 150)) < 0.01
+    planted = np.where(mut, (planted + rng.integers(1, 4, (half, 150))) & 3, planted).astype(np.uint8)
+    codes = np.concatenate([planted, rng.integers(0, 4, (n - half, 150), dtype=np.uint8)])
+    seq = synth.CODE2BASE[codes]                       # [n, 150] ASCII
+    rec = np.empty((n, 12 + 1 + 150 + 3 + 150 + 1), dtype=np.uint8)
+    names = np.char.zfill(np.arange(n).astype(str), 10)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    rec[:, 2:12] = np.frombuffer("".join(names).encode(), dtype=np.uint8).reshape(n, 10)
+    rec[:, 12] = 10
+    rec[:, 13:163] = seq
+    rec[:, 163] = 10; rec[:, 164] = ord("+"); rec[:, 165] = 10
+    rec[:, 166:316] = ord("I")
+    rec[:, 316] = 10
+    fq = work + "/reads.fq"
+    rec.tofile(fq)
+    print("generated %d reads (%.2f GB) in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
+    exe = os.path.join(ROOT, "bin", "cuCLARK-l")
+    for run in range(2):
+        t0 = time.time()
+        r = subprocess.run([exe, "-T", work + "/targets.txt", "-D", work + "/db", "-O", fq, "-R", work + "/res",
+                            "-n", threads, "-b", "32", "--verbose"], capture_output=True, text=True)
+        dt = time.time() - t0
+        tail = [l for l in r.stderr.split("\n") if "Done in" in l or "timing" in l]
+        print("run %d: rc=%d wall %.2fs  %s" % (run, r.returncode, dt, " | ".join(tail)), flush=True)
+    lines = sum(1 for _ in open(work + "/res.csv"))
+    print("csv lines:", lines)
+
+
+if __name__ == "__main__":
+    main()
