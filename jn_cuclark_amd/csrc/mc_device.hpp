@@ -212,6 +212,9 @@ __device__ __forceinline__ bool part_find(const u32x4 v, uint32_t q, bool active
 #ifndef MC_MIN_WAVES
 #define MC_MIN_WAVES 1
 #endif
+#ifndef MC_NSLOT
+#define MC_NSLOT 2      // k-mers per lane per step (both probes in flight together)
+#endif
 template <int LINE>
 __global__ __launch_bounds__(BLOCK_THREADS, MC_MIN_WAVES)
 void query_kernel(const QueryArgs a)
@@ -285,12 +288,13 @@ void query_kernel(const QueryArgs a)
                 if (plen < k) continue;
                 const uint32_t nk = plen - k + 1u;
 
-                for (uint32_t base = 0; base < nk; base += 128u) {
+                for (uint32_t base = 0; base < nk; base += 64u * MC_NSLOT) {
                     constexpr int LPP = LINE / 16;        // lanes per probe
                     constexpr int PPR = 64 / LPP;         // probes per round
-                    uint32_t q32[2], lidx[2];
+                    constexpr int NSLOT = MC_NSLOT;
+                    uint32_t q32[NSLOT], lidx[NSLOT];
 #pragma unroll
-                    for (int s = 0; s < 2; s++) {
+                    for (int s = 0; s < NSLOT; s++) {
                         const uint32_t p = base + 64u * s + lane;
                         q32[s] = 0; lidx[s] = LIDX_NONE;
                         if (p < nk) {
@@ -315,10 +319,10 @@ void query_kernel(const QueryArgs a)
                     }
                     // issue every line fetch of the step (2 slots x LPP rounds) before using any
                     const uint32_t part = lane & (LPP - 1);
-                    uint32_t gq[2][LPP], gl[2][LPP];
-                    u32x4 gv[2][LPP];
+                    uint32_t gq[NSLOT][LPP], gl[NSLOT][LPP];
+                    u32x4 gv[NSLOT][LPP];
 #pragma unroll
-                    for (int s = 0; s < 2; s++) {
+                    for (int s = 0; s < NSLOT; s++) {
 #pragma unroll
                         for (int j = 0; j < LPP; j++) {
                             const int src = j * PPR + (int)(lane / LPP);
@@ -330,10 +334,10 @@ void query_kernel(const QueryArgs a)
                     }
                     // after the LPP rounds lane l holds the result of probe PPR*(l%LPP) + l/LPP:
                     // a permutation of the step's probes, which is all the counting needs
-                    bool     hit[2];
-                    uint32_t lab[2];
+                    bool     hit[NSLOT];
+                    uint32_t lab[NSLOT];
 #pragma unroll
-                    for (int s = 0; s < 2; s++) {
+                    for (int s = 0; s < NSLOT; s++) {
                         hit[s] = false; lab[s] = 0;
 #pragma unroll
                         for (int j = 0; j < LPP; j++) {
@@ -346,18 +350,30 @@ void query_kernel(const QueryArgs a)
 
                     // fold the hits of this step into the accumulator, one distinct
                     // target per iteration (wave-uniform control flow)
-                    uint64_t m0 = __ballot(hit[0]);
-                    uint64_t m1 = __ballot(hit[1]);
-                    while (m0 | m1) {
-                        uint32_t t;
-                        if (m0) t = (uint32_t)__shfl((int)lab[0], __ffsll((unsigned long long)m0) - 1, 64);
-                        else    t = (uint32_t)__shfl((int)lab[1], __ffsll((unsigned long long)m1) - 1, 64);
-                        const uint64_t s0 = __ballot(hit[0] && lab[0] == t);
-                        const uint64_t s1 = __ballot(hit[1] && lab[1] == t);
-                        const uint32_t cnt = (uint32_t)(__popcll(s0) + __popcll(s1));
-                        m0 &= ~s0; m1 &= ~s1;
-                        if (lab[0] == t) hit[0] = false;
-                        if (lab[1] == t) hit[1] = false;
+                    uint64_t m[NSLOT];
+                    uint64_t many = 0;
+#pragma unroll
+                    for (int s = 0; s < NSLOT; s++) { m[s] = __ballot(hit[s]); many |= m[s]; }
+                    while (many) {
+                        uint32_t t = 0;
+                        bool got = false;
+#pragma unroll
+                        for (int s = 0; s < NSLOT; s++) {
+                            if (!got && m[s]) {
+                                t = (uint32_t)__shfl((int)lab[s], __ffsll((unsigned long long)m[s]) - 1, 64);
+                                got = true;
+                            }
+                        }
+                        uint32_t cnt = 0;
+                        many = 0;
+#pragma unroll
+                        for (int s = 0; s < NSLOT; s++) {
+                            const uint64_t same = __ballot(hit[s] && lab[s] == t);
+                            cnt += (uint32_t)__popcll(same);
+                            m[s] &= ~same;
+                            many |= m[s];
+                            if (lab[s] == t) hit[s] = false;
+                        }
 
                         const uint64_t ex = __ballot(acc_t == t);
                         if (ex) {

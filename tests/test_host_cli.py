@@ -186,3 +186,41 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
     flat = np.concatenate([p[:-1].astype(np.int64) + s for p, s in zip(ptrs, starts)] + [[con.size]])
     assert np.array_equal(flat, rp.astype(np.int64))
     assert "Done in" in r.stderr and "reads/min" in r.stderr
+
+
+def test_runs_under_the_reference_classify_script(tmp_path):
+    """drop-in under scripts/classify_metagenome.sh (reference :155-159 execs ../bin/cuCLARK[-l]
+    with .settings + its own arguments).  The script is run from a scratch copy made at
+    test time (it needs a writable .settings next to it); only where /root/reference exists.
+    Without a GPU the run stops where the device is opened, after the database build."""
+    import shutil
+    ref_script = "/root/reference/scripts/classify_metagenome.sh"
+    if not os.path.exists(ref_script):
+        pytest.skip("reference scripts not present on this machine")
+    _build()
+    (tmp_path / "scripts").mkdir()
+    (tmp_path / "bin").mkdir()
+    shutil.copy(ref_script, str(tmp_path / "scripts" / "classify_metagenome.sh"))
+    for exe in ("cuCLARK", "cuCLARK-l"):
+        os.symlink(os.path.join(BIN, exe), str(tmp_path / "bin" / exe))
+    genomes = synth.toy_genomes(3, 3000, seed=81)
+    targets = _write_targets(tmp_path, genomes, ["A", "B", "C"], n_mask=False)
+    dbdir = tmp_path / "custom_0"
+    dbdir.mkdir()
+    (tmp_path / "scripts" / ".settings").write_text("-T %s\n-D %s/\n" % (targets, dbdir))
+    reads = tmp_path / "reads.fa"
+    reads.write_bytes(synth.fasta_text([b"r%d" % i for i in range(20)],
+                                       [synth.codes_to_ascii(genomes[i % 3][10 * i:10 * i + 150]) for i in range(20)]))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "jn_cuclark_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(["sh", "./classify_metagenome.sh", "-O", str(reads), "-R", str(tmp_path / "out"),
+                        "-n", "2", "-b", "4", "--light"], cwd=str(tmp_path / "scripts"),
+                       capture_output=True, text=True, timeout=600, env=env)
+    base = dbdir / "db_central_k27_t3_s57777779_m0_light_4.tsk"
+    assert os.path.exists(str(base) + ".ky"), r.stderr
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+        assert open(str(tmp_path / "out.csv")).readline().startswith("Object_ID,Gamma,Assignment")
+    else:
+        assert "No HIP devices" in r.stderr
+    os.remove(str(base) + ".sz")
