@@ -255,3 +255,35 @@ def test_errors_are_reported_not_fatal(gpu):
             db.malloc(10, 100)
             db.readyBatch(0, 1, 3)
             db.queryBatch(0)                                              # no database yet
+
+
+def test_two_byte_keys_and_sharded_file_load(gpu, oracle, tmp_path):
+    """k small enough for 2-byte quotients (reference T16 regime, main.cc:255-263): the
+    .ky file holds u16, widened on the device; also a bucket-range shard read from files."""
+    k, ht = 17, 1000003
+    genomes = synth.toy_genomes(5, 4000, seed=91, shared=100)
+    sz, ky, lb = synth.genome_db(genomes, k, ht)
+    assert ky.max() < 65536
+    nzb = np.flatnonzero(sz)
+    canon = np.repeat(nzb, sz[nzb]).astype(np.uint64) + ky.astype(np.uint64) * np.uint64(ht)
+    base = str(tmp_path / "db16")
+    oracle.db_write(base, ht, 2, canon, lb)
+    assert os.path.getsize(base + ".ky") == 2 * ky.size
+    codes, _ = synth.sample_reads(genomes, 1500, 120, seed=3)
+    rp, con = synth.pack_uniform(codes)
+    odb = oracle.OracleDB.load(base, ht, 2)
+    want, _ = odb.classify(k, rp, con, 15)
+    assert (want[:, 2] > 0).sum() > 1000
+    with gpu(k=k, numBatches=1, numTargets=5, device=0, htsize=ht, maxhits=15) as db:
+        assert db.read(base, key_bytes=2) is True
+        assert np.array_equal(db.classify(rp, con), want)
+    with gpu(k=k, numBatches=1, numTargets=5, device=0, htsize=ht, maxhits=15) as db:
+        db.read_arrays(sz, ky.astype(np.uint16), lb)
+        assert np.array_equal(db.classify(rp, con), want)
+    # shard [a, b) straight from the files == oracle restricted to the same bucket range
+    a, b = ht // 3, 2 * ht // 3
+    rows_want, _ = odb.query_rows(k, rp, con, 15, part=(a, b))
+    with gpu(k=k, numBatches=1, numTargets=5, device=0, htsize=ht, maxhits=15) as db:
+        assert db.read(base, key_bytes=2, shard=(a, b)) is True
+        _, rows = db.classify(rp, con, extended=True)
+    assert np.array_equal(rows, rows_want)
