@@ -82,9 +82,9 @@ int mc_api_version(void);
 int mc_device_count(int *count);
 
 /* Create a context on `device` (-1 = current HIP device).
- * replaces: CuClarkDB::CuClarkDB (CuClarkDB.cu:94-241).  k in [2,32] with
- * (4^k-1)/htsize < 2^32-1 (the reference's 4-byte-key regime, main.cc:267-275, which
- * covers k=31 full and k=27 light); num_targets = targetsName.size()-1;
+ * replaces: CuClarkDB::CuClarkDB (CuClarkDB.cu:94-241).  k in [2,32]; when some
+ * quotient (4^k-1)/htsize does not fit 32 bits (the reference's T64 regime, k = 32,
+ * main.cc:277-286) the table uses 64-bit keys.  num_targets = targetsName.size()-1;
  * maxhits = MAXHITS (15 full / 23 light), at most 63. */
 int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize,
             uint32_t num_targets, uint32_t maxhits);
@@ -93,7 +93,7 @@ int mc_close(mc_ctx *ctx);
 /* Load <base>.sz/.ky/.lb, keep the buckets [shard_begin, shard_end) (0,0 = all),
  * upload and re-lay them out as bucket lines in HBM.
  * replaces: CuClarkDB::read + swapDbParts (CuClarkDB.cu:463-815).  key_bytes =
- * sizeof(HKMERr) of the files (2 or 4).  sampling = the -s factor (<=1: none,
+ * sizeof(HKMERr) of the files (2, 4 or 8).  sampling = the -s factor (<=1: none,
  * CuClarkDB.cu:490-513).  MC_EIO when a file is missing (the reference returns
  * false and the caller rebuilds, CuCLARK_hh.hh:622-684). */
 int mc_load_db(mc_ctx *ctx, const char *base, int key_bytes, uint32_t sampling,
@@ -105,8 +105,8 @@ int mc_load_db_host(mc_ctx *ctx, const uint8_t *sz, const void *keys, int key_by
                     uint64_t shard_begin, uint64_t shard_end);
 
 /* Same, from arrays already in HBM on ctx's device: d_sz covers buckets
- * [shard_begin, shard_end) only, d_keys (u32) / d_labels their n_keys elements. */
-int mc_load_db_device(mc_ctx *ctx, const uint8_t *d_sz, const uint32_t *d_keys,
+ * [shard_begin, shard_end) only, d_keys (key_bytes each) / d_labels their n_keys elements. */
+int mc_load_db_device(mc_ctx *ctx, const uint8_t *d_sz, const void *d_keys, int key_bytes,
                       const uint16_t *d_labels, uint64_t n_keys,
                       uint64_t shard_begin, uint64_t shard_end);
 

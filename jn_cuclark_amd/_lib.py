@@ -44,7 +44,7 @@ SYMBOLS = [
     ("mc_close", _i, [_vp]),
     ("mc_load_db", _i, [_vp, C.c_char_p, _i, _u32, _u64, _u64]),
     ("mc_load_db_host", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
-    ("mc_load_db_device", _i, [_vp, _vp, _vp, _vp, _u64, _u64, _u64]),
+    ("mc_load_db_device", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
     ("mc_get_db_info", _i, [_vp, C.POINTER(McDbInfo)]),
     ("mc_get_stats", _i, [_vp, C.POINTER(McStats)]),
     ("mc_alloc_batches", _i, [_vp, _u32, _u64, _u64, _i]),

@@ -84,16 +84,16 @@ class CuClarkDB:
         sz = np.ascontiguousarray(sz, dtype=np.uint8)
         keys = np.ascontiguousarray(keys)
         labels = np.ascontiguousarray(labels, dtype=np.uint16)
-        if keys.dtype not in (np.uint16, np.uint32):
-            raise ValueError("keys must be uint16 or uint32")
+        if keys.dtype not in (np.uint16, np.uint32, np.uint64):
+            raise ValueError("keys must be uint16, uint32 or uint64")
         check(self._lib.mc_load_db_host(self._h, sz.ctypes.data, keys.ctypes.data, keys.dtype.itemsize,
                                         labels.ctypes.data, keys.size, int(shard[0]), int(shard[1])))
         self._cycles_to_do = 1
 
     def read_device(self, d_sz, d_keys, d_labels, shard=(0, 0)):
-        """Raw arrays already in HBM (torch uint8 / int32 / int16 tensors on this device)."""
-        check(self._lib.mc_load_db_device(self._h, _ptr(d_sz), _ptr(d_keys), _ptr(d_labels),
-                                          int(d_keys.numel()), int(shard[0]), int(shard[1])))
+        """Raw arrays already in HBM (torch uint8 / int16|int32|int64 / int16 tensors on this device)."""
+        check(self._lib.mc_load_db_device(self._h, _ptr(d_sz), _ptr(d_keys), int(d_keys.element_size()),
+                                          _ptr(d_labels), int(d_keys.numel()), int(shard[0]), int(shard[1])))
         self._cycles_to_do = 1
 
     def db_info(self):

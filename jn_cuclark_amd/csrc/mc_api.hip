@@ -83,6 +83,7 @@ struct mc_ctx {
     uint32_t k = 0, num_targets = 0, maxhits = 0;
     uint64_t htsize = 0;
     mc::DivU64 div{};
+    bool wide = false;          // quotients need 64 bits (reference T64 regime: k = 32)
     int n_cu = 0;
 
     hipStream_t streams[2] = {nullptr, nullptr};
@@ -90,7 +91,7 @@ struct mc_ctx {
     // database
     bool db_loaded = false;
     uint8_t *d_lines = nullptr;
-    uint32_t *d_ovf_keys = nullptr;
+    void *d_ovf_keys = nullptr;
     uint16_t *d_ovf_labels = nullptr;
     mc_db_info info{};
     int grid_blocks = 0;
@@ -123,18 +124,28 @@ void free_db(mc_ctx *c)
     c->db_loaded = false;
 }
 
-template <int LINE>
-int launch_fill(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint16_t *d_labels,
+template <int LINE, bool WIDE>
+int launch_fill(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
                 uint64_t nb, const uint64_t *d_koff, const uint64_t *d_ooff, uint32_t nblk)
 {
-    hipLaunchKernelGGL(mc::fill_lines_kernel<LINE>, dim3(nblk), dim3(mc::RL_THREADS), 0, c->streams[0],
-                       d_sz, d_keys, d_labels, nb, d_koff, d_ooff, c->d_lines, c->d_ovf_keys, c->d_ovf_labels);
+    typedef typename mc::KeyOf<WIDE>::type key_t;
+    hipLaunchKernelGGL((mc::fill_lines_kernel<LINE, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, c->streams[0],
+                       d_sz, static_cast<const key_t *>(d_keys), d_labels, nb, d_koff, d_ooff, c->d_lines,
+                       static_cast<key_t *>(c->d_ovf_keys), c->d_ovf_labels);
     HIPCHK(hipGetLastError());
     return MC_OK;
 }
 
-// Build the bucket lines from raw arrays resident on the device.
-int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint16_t *d_labels,
+template <int LINE, bool WIDE>
+int query_occupancy(int &occ)
+{
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::query_kernel<LINE, WIDE>, mc::BLOCK_THREADS, 0));
+    return MC_OK;
+}
+
+// Build the bucket lines from raw arrays resident on the device; d_keys holds u32
+// quotients, or u64 when the context is in wide-key mode.
+int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
              uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
 {
     const uint64_t nb = shard_end - shard_begin;
@@ -162,9 +173,12 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint1
     auto over = [&](int cap) { uint64_t b = 0; for (int i = cap + 1; i < 256; i++) b += hist[i]; return b; };
     // 64-byte lines unless more than 3 % of the non-empty buckets would overflow them
     const char *force = getenv("MC_LINE_BYTES");
-    uint32_t line = (nonempty == 0 || over(mc::LineCfg<64>::CAP) * 100 <= nonempty * 3) ? 64u : 128u;
+    const int cap64 = c->wide ? mc::LineCfg<64, true>::CAP : mc::LineCfg<64, false>::CAP;
+    const int cap128 = c->wide ? mc::LineCfg<128, true>::CAP : mc::LineCfg<128, false>::CAP;
+    uint32_t line = (nonempty == 0 || over(cap64) * 100 <= nonempty * 3) ? 64u : 128u;
     if (force && (atoi(force) == 64 || atoi(force) == 128)) line = (uint32_t)atoi(force);
-    const int cap = line == 64 ? mc::LineCfg<64>::CAP : mc::LineCfg<128>::CAP;
+    const int cap = line == 64 ? cap64 : cap128;
+    const size_t kb = c->wide ? 8 : 4;
     uint64_t n_ovf_b = 0, n_ovf_k = 0;
     for (int i = cap + 1; i < 256; i++) { n_ovf_b += hist[i]; n_ovf_k += hist[i] * (uint64_t)i; }
 
@@ -197,10 +211,13 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint1
         (void)hipFree(d_koff); (void)hipFree(d_ooff);
         return fail(MC_ENOMEM, "hipMalloc of " + std::to_string(line_bytes) + " bytes of bucket lines failed");
     }
-    HIPCHK(hipMalloc(&c->d_ovf_keys, (size_t)(n_ovf_k ? n_ovf_k : 4) * 4));
+    HIPCHK(hipMalloc(&c->d_ovf_keys, (size_t)(n_ovf_k ? n_ovf_k : 4) * kb));
     HIPCHK(hipMalloc(&c->d_ovf_labels, (size_t)(n_ovf_k ? n_ovf_k : 4) * 2));
-    int rc = line == 64 ? launch_fill<64>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk)
-                        : launch_fill<128>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk);
+    int rc;
+    if (!c->wide) rc = line == 64 ? launch_fill<64, false>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk)
+                                  : launch_fill<128, false>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk);
+    else          rc = line == 64 ? launch_fill<64, true>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk)
+                                  : launch_fill<128, true>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk);
     if (rc != MC_OK) return rc;
     HIPCHK(hipStreamSynchronize(st));
     (void)hipFree(d_koff); (void)hipFree(d_ooff);
@@ -213,12 +230,13 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint1
     c->info.n_overflow_keys = n_ovf_k;
     c->info.line_bytes = line;
     c->info.line_capacity = (uint32_t)cap;
-    c->info.device_bytes = line_bytes + n_ovf_k * 6;
+    c->info.device_bytes = line_bytes + n_ovf_k * (kb + 2);
 
     // persistent grid: as many workgroups as stay resident
     int occ = 0;
-    if (line == 64) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::query_kernel<64>, mc::BLOCK_THREADS, 0));
-    else            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::query_kernel<128>, mc::BLOCK_THREADS, 0));
+    if (!c->wide) rc = line == 64 ? query_occupancy<64, false>(occ) : query_occupancy<128, false>(occ);
+    else          rc = line == 64 ? query_occupancy<64, true>(occ) : query_occupancy<128, true>(occ);
+    if (rc != MC_OK) return rc;
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
     if (const char *e = getenv("MC_GRID_OCC")) {          // tuning knob: resident workgroups per CU
@@ -227,6 +245,37 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint1
     }
     c->grid_blocks = occ * c->n_cu;
     c->db_loaded = true;
+    return MC_OK;
+}
+
+template <typename IN, typename OUT>
+int widen(mc_ctx *c, const void *in, uint64_t n, void *out)
+{
+    hipLaunchKernelGGL((mc::widen_keys_kernel<IN, OUT>), dim3(c->n_cu * 8), dim3(256), 0, c->streams[0],
+                       static_cast<const IN *>(in), n, static_cast<OUT *>(out));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->streams[0]));
+    return MC_OK;
+}
+
+// d_raw: n quotients of key_bytes each (the width of the .ky file).  *out: the same
+// quotients in the context's key width.  When the widths agree *out = d_raw; otherwise a
+// new array (and d_raw is freed if raw_owned).  *out_owned: caller frees *out.
+int convert_keys(mc_ctx *c, void *d_raw, int key_bytes, uint64_t n, bool raw_owned, void **out, bool *out_owned)
+{
+    const int want = c->wide ? 8 : 4;
+    if (key_bytes == want) { *out = d_raw; *out_owned = raw_owned; return MC_OK; }
+    if (key_bytes > want)
+        return fail(MC_EINVAL, "8-byte key file for a k/htsize whose quotients fit 4 bytes: rebuild the database "
+                               "(the reference writes 4-byte keys here, src/main.cc:267-275)");
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, (n ? n : 1) * (size_t)want));
+    int rc;
+    if (key_bytes == 2) rc = c->wide ? widen<uint16_t, uint64_t>(c, d_raw, n, d) : widen<uint16_t, uint32_t>(c, d_raw, n, d);
+    else                rc = widen<uint32_t, uint64_t>(c, d_raw, n, d);
+    if (raw_owned) (void)hipFree(d_raw);
+    if (rc != MC_OK) { (void)hipFree(d); return rc; }
+    *out = d; *out_owned = true;
     return MC_OK;
 }
 
@@ -262,10 +311,14 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     const uint64_t n_groups = (n_reads + mc::GROUP_READS - 1) / mc::GROUP_READS;
     const uint64_t want = (n_groups + mc::WAVES_PER_BLOCK - 1) / mc::WAVES_PER_BLOCK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->grid_blocks);
-    if (c->info.line_bytes == 64)
-        hipLaunchKernelGGL(mc::query_kernel<64>, dim3(grid), dim3(mc::BLOCK_THREADS), 0, st, a);
-    else
-        hipLaunchKernelGGL(mc::query_kernel<128>, dim3(grid), dim3(mc::BLOCK_THREADS), 0, st, a);
+    const dim3 g(grid), b(mc::BLOCK_THREADS);
+    if (!c->wide) {
+        if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, false>), g, b, 0, st, a);
+        else                          hipLaunchKernelGGL((mc::query_kernel<128, false>), g, b, 0, st, a);
+    } else {
+        if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, true>), g, b, 0, st, a);
+        else                          hipLaunchKernelGGL((mc::query_kernel<128, true>), g, b, 0, st, a);
+    }
     HIPCHK(hipGetLastError());
     c->stats.reads += n_reads;
     c->stats.kernel_launches++;
@@ -295,10 +348,10 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     if (k < 2 || k > 32) return fail(MC_EINVAL, "k must be in [2,32]");
     if (htsize < 2) return fail(MC_EINVAL, "htsize must be >= 2");
     if (maxhits < 1 || maxhits > 63) return fail(MC_EINVAL, "maxhits must be in [1,63]");
-    // 4-byte-key regime: every quotient must be < 0xFFFFFFFF (the line sentinel)
+    if (htsize >= 0xFFFFFFFFull) return fail(MC_EINVAL, "htsize must be < 2^32-1 (bucket indices are 32-bit, reference ITYPE)");
+    // narrow lines need every quotient < 0xFFFFFFFF (the sentinel); otherwise 64-bit keys
     const unsigned __int128 maxkmer = k == 32 ? (unsigned __int128)~0ull : (((unsigned __int128)1 << (2 * k)) - 1);
-    if (maxkmer / htsize >= 0xFFFFFFFFull)
-        return fail(MC_EINVAL, "k/htsize combination needs keys wider than 32 bits (reference T64 regime): not supported");
+    const bool wide = maxkmer / htsize >= 0xFFFFFFFFull;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(MC_ENODEVICE, "no HIP device visible");
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
@@ -306,6 +359,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     mc_ctx *c = new mc_ctx();
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
     c->div = make_div(htsize);
+    c->wide = wide;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -331,20 +385,26 @@ int mc_close(mc_ctx *c)
     return MC_OK;
 }
 
-int mc_load_db_device(mc_ctx *c, const uint8_t *d_sz, const uint32_t *d_keys, const uint16_t *d_labels,
+int mc_load_db_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int key_bytes, const uint16_t *d_labels,
                       uint64_t n_keys, uint64_t sb, uint64_t se)
 {
     if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
     int rc = set_dev(c); if (rc) return rc;
     rc = norm_shard(c, sb, se); if (rc) return rc;
-    return relayout(c, d_sz, d_keys, d_labels, n_keys, sb, se);
+    void *keys = nullptr; bool owned = false;
+    rc = convert_keys(c, const_cast<void *>(d_keys), key_bytes, n_keys, false, &keys, &owned);
+    if (rc) return rc;
+    rc = relayout(c, d_sz, keys, d_labels, n_keys, sb, se);
+    if (owned) (void)hipFree(keys);
+    return rc;
 }
 
 int mc_load_db_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,
                     uint64_t n_keys, uint64_t sb, uint64_t se)
 {
     if (!c) return fail(MC_EINVAL, "ctx is NULL");
-    if (key_bytes != 2 && key_bytes != 4) return fail(MC_EINVAL, "key_bytes must be 2 or 4");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
     int rc = set_dev(c); if (rc) return rc;
     rc = norm_shard(c, sb, se); if (rc) return rc;
     // keys of the shard are one contiguous run of the arrays
@@ -353,25 +413,18 @@ int mc_load_db_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_byte
     for (uint64_t b = sb; b < se; b++) kn += sz[b];
     if (k0 + kn > n_keys) return fail(MC_EINVAL, "bucket sizes exceed n_keys");
     const uint64_t nb = se - sb;
-    uint8_t *d_sz = nullptr; uint32_t *d_keys = nullptr; uint16_t *d_labels = nullptr; uint16_t *d_k16 = nullptr;
+    uint8_t *d_sz = nullptr; void *d_raw = nullptr; uint16_t *d_labels = nullptr;
     HIPCHK(hipMalloc(&d_sz, nb ? nb : 1));
-    HIPCHK(hipMalloc(&d_keys, (kn ? kn : 1) * 4));
+    HIPCHK(hipMalloc(&d_raw, (kn ? kn : 1) * (size_t)key_bytes));
     HIPCHK(hipMalloc(&d_labels, (kn ? kn : 1) * 2));
     HIPCHK(hipMemcpy(d_sz, sz + sb, nb, hipMemcpyHostToDevice));
     if (kn) {
-        if (key_bytes == 4) {
-            HIPCHK(hipMemcpy(d_keys, (const uint32_t *)keys + k0, kn * 4, hipMemcpyHostToDevice));
-        } else {
-            HIPCHK(hipMalloc(&d_k16, kn * 2));
-            HIPCHK(hipMemcpy(d_k16, (const uint16_t *)keys + k0, kn * 2, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(mc::widen_keys_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->streams[0], d_k16, kn, d_keys);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(c->streams[0]));
-            (void)hipFree(d_k16);
-        }
+        HIPCHK(hipMemcpy(d_raw, (const char *)keys + k0 * (size_t)key_bytes, kn * (size_t)key_bytes, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_labels, labels + k0, kn * 2, hipMemcpyHostToDevice));
     }
-    rc = relayout(c, d_sz, d_keys, d_labels, kn, sb, se);
+    void *d_keys = nullptr; bool owned = false;
+    rc = convert_keys(c, d_raw, key_bytes, kn, true, &d_keys, &owned);
+    if (rc == MC_OK) rc = relayout(c, d_sz, d_keys, d_labels, kn, sb, se);
     (void)hipFree(d_sz); (void)hipFree(d_keys); (void)hipFree(d_labels);
     return rc;
 }
@@ -379,7 +432,7 @@ int mc_load_db_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_byte
 int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, uint64_t sb, uint64_t se)
 {
     if (!c || !base) return fail(MC_EINVAL, "ctx/base is NULL");
-    if (key_bytes != 2 && key_bytes != 4) return fail(MC_EINVAL, "key_bytes must be 2 or 4");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
     int rc = set_dev(c); if (rc) return rc;
     rc = norm_shard(c, sb, se); if (rc) return rc;
     const std::string b(base);
@@ -406,11 +459,10 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
         else if (i < se && kp) kept += sz[i];
     }
     const uint64_t nb = se - sb;
-    uint8_t *d_sz = nullptr; uint32_t *d_keys = nullptr; uint16_t *d_labels = nullptr; uint16_t *d_k16 = nullptr;
+    uint8_t *d_sz = nullptr; char *d_raw = nullptr; uint16_t *d_labels = nullptr;
     HIPCHK(hipMalloc(&d_sz, nb ? nb : 1));
-    HIPCHK(hipMalloc(&d_keys, (kept ? kept : 1) * 4));
+    HIPCHK(hipMalloc(&d_raw, (kept ? kept : 1) * (size_t)key_bytes));
     HIPCHK(hipMalloc(&d_labels, (kept ? kept : 1) * 2));
-    if (key_bytes == 2) HIPCHK(hipMalloc(&d_k16, (kept ? kept : 1) * 2));
 
     // stream the shard's keys/labels through a staging buffer, dropping unsampled buckets
     const uint64_t CH = 1ull << 24;   // buckets per step
@@ -442,8 +494,7 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
             nkeep = w;
         }
         if (nkeep) {
-            if (key_bytes == 4) HIPCHK(hipMemcpy(d_keys + dpos, kbuf.data(), nkeep * 4, hipMemcpyHostToDevice));
-            else                HIPCHK(hipMemcpy(d_k16 + dpos, kbuf.data(), nkeep * 2, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_raw + dpos * (size_t)key_bytes, kbuf.data(), nkeep * (size_t)key_bytes, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(d_labels + dpos, lbuf.data(), nkeep * 2, hipMemcpyHostToDevice));
         }
         fpos += nfile; dpos += nkeep;
@@ -451,13 +502,9 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
     closeall();
     if (dpos != kept) return fail(MC_EINVAL, "internal: kept-key count mismatch");
     HIPCHK(hipMemcpy(d_sz, sz.data() + sb, nb, hipMemcpyHostToDevice));
-    if (key_bytes == 2) {
-        hipLaunchKernelGGL(mc::widen_keys_kernel, dim3(c->n_cu * 8), dim3(256), 0, c->streams[0], d_k16, kept, d_keys);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->streams[0]));
-        (void)hipFree(d_k16);
-    }
-    rc = relayout(c, d_sz, d_keys, d_labels, kept, sb, se);
+    void *d_keys = nullptr; bool owned = false;
+    rc = convert_keys(c, d_raw, key_bytes, kept, true, &d_keys, &owned);
+    if (rc == MC_OK) rc = relayout(c, d_sz, d_keys, d_labels, kept, sb, se);
     (void)hipFree(d_sz); (void)hipFree(d_keys); (void)hipFree(d_labels);
     return rc;
 }

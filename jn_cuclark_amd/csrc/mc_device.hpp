@@ -51,9 +51,15 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t n, const DivU64 &dv)
 
 // ---------------------------------------------------------------------------
 // bucket lines
-//   LINE bytes per bucket, CAP = (LINE-4)/6 k-mers:
+//   LINE bytes per bucket.  Narrow keys (quotient < 2^32-1: every k <= 31 of the
+//   reference's two table sizes), CAP = (LINE-4)/6 k-mers:
 //     dword [0, CAP)            keys (quotients, ascending; unused = 0xFFFFFFFF)
 //     dword [CAP, CAP+CAP/2)    labels, two u16 per dword
+//   Wide keys (WIDE: quotients need 64 bits, the reference's T64 regime, k = 32,
+//   src/main.cc:277-286), CAP = (LINE-4)/10 k-mers:
+//     dword [0, 2*CAP)          keys as (lo, hi) pairs, unused = all ones
+//     dword [2*CAP, 2*CAP+CAP/2) labels
+//   Both:
 //     dword LINE/4-1            header: low byte = number of keys, or 0xFF when the
 //                               bucket did not fit: then dword0|dword1<<32 = offset
 //                               into the overflow arrays and dword2 = its size.
@@ -61,12 +67,15 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t n, const DivU64 &dv)
 static constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
 static constexpr uint32_t HDR_OVERFLOW = 0xFFu;
 
-template <int LINE> struct LineCfg {
+template <int LINE, bool WIDE = false> struct LineCfg {
     static constexpr int DW   = LINE / 4;
-    static constexpr int CAP  = (LINE - 4) / 6;
-    static constexpr int LAB0 = CAP;       // first label dword
+    static constexpr int CAP  = WIDE ? (LINE - 4) / 10 : (LINE - 4) / 6;
+    static constexpr int KDW  = WIDE ? 2 : 1;          // dwords per key
+    static constexpr int LAB0 = CAP * KDW;             // first label dword
     static constexpr int HDR  = DW - 1;
 };
+template <bool WIDE> struct KeyOf { typedef uint32_t type; };
+template <> struct KeyOf<true> { typedef uint64_t type; };
 
 struct QueryArgs {
     const uint32_t *reads_ptr;      // n_reads+1 container offsets (ref :1034-1035)
@@ -74,7 +83,7 @@ struct QueryArgs {
     uint64_t n_reads;
     uint64_t n_containers;
     const uint8_t  *lines;          // bucket lines of this shard
-    const uint32_t *ovf_keys;
+    const void     *ovf_keys;       // u32 (narrow) or u64 (wide) quotients of oversized buckets
     const uint16_t *ovf_labels;
     uint64_t shard_begin;           // ref dbPartStart / dbPartEnd (:1212-1214)
     uint64_t shard_end;
@@ -162,23 +171,33 @@ __device__ __forceinline__ u32x4 part_load(const uint8_t *lines, uint32_t lidx, 
 // group's probe, whose quotient is q.  Returns hit/label for the group's probe (the
 // same value in every lane of the group).  Lowest matching index wins, like the
 // ascending scan of reference CuClarkDB.cu:1236-1247.
-template <int LINE>
-__device__ __forceinline__ bool part_find(const u32x4 v, uint32_t q, bool active, uint32_t lane,
-                                          const uint32_t *ovf_keys, const uint16_t *ovf_labels,
+template <int LINE, bool WIDE>
+__device__ __forceinline__ bool part_find(const u32x4 v, uint64_t q, bool active, uint32_t lane,
+                                          const void *ovf_keys_v, const uint16_t *ovf_labels,
                                           uint32_t &label)
 {
-    using C = LineCfg<LINE>;
+    using C = LineCfg<LINE, WIDE>;
+    typedef typename KeyOf<WIDE>::type key_t;
     constexpr int LPP = LINE / 16;
     const uint32_t part = lane & (LPP - 1);
     const uint32_t gbase = lane & ~(uint32_t)(LPP - 1);
     uint32_t midx = 0xFFu;
+    if (!WIDE) {
 #pragma unroll
-    for (int d = 3; d >= 0; d--) {
-        const uint32_t gd = part * 4u + (uint32_t)d;
-        if (active && gd < (uint32_t)C::CAP && v[d] == q) midx = gd;
+        for (int d = 3; d >= 0; d--) {
+            const uint32_t gd = part * 4u + (uint32_t)d;
+            if (active && gd < (uint32_t)C::CAP && v[d] == (uint32_t)q) midx = gd;
+        }
+    } else {
+#pragma unroll
+        for (int d = 1; d >= 0; d--) {
+            const uint32_t gd = part * 2u + (uint32_t)d;      // key index
+            const uint64_t key = (uint64_t)v[2 * d] | ((uint64_t)v[2 * d + 1] << 32);
+            if (active && gd < (uint32_t)C::CAP && key == q) midx = gd;
+        }
     }
     midx = group_min<LPP>(midx);
-    // label dword of key midx: global dword CAP + midx/2 -> lane (that/4), register (that%4)
+    // label dword of key midx: global dword LAB0 + midx/2 -> lane (that/4), register (that%4)
     const uint32_t ld = (uint32_t)C::LAB0 + ((midx & 0x7Fu) >> 1);
     const uint32_t sel = ld & 3u;
     const uint32_t cand = sel == 0 ? v[0] : sel == 1 ? v[1] : sel == 2 ? v[2] : v[3];
@@ -189,13 +208,14 @@ __device__ __forceinline__ bool part_find(const u32x4 v, uint32_t q, bool active
     // buckets that did not fit a line (header 0xFF): rare, handled by group lane 0
     const bool ovf_here = active && part == (uint32_t)(LPP - 1) && (v[3] & 0xFFu) == HDR_OVERFLOW;
     if (__ballot(ovf_here)) {
+        const key_t *ovf_keys = static_cast<const key_t *>(ovf_keys_v);
         const bool ovf = __shfl((int)ovf_here, (int)(gbase + LPP - 1), 64) != 0;
         uint32_t res = 0;                               // bit 16 = hit, low 16 = label
         if (ovf && part == 0) {
             const uint64_t off = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
             const uint32_t n = v[2];
             for (uint32_t i = 0; i < n; i++) {
-                const uint32_t key = ovf_keys[off + i];
+                const uint64_t key = ovf_keys[off + i];
                 if (key == q) { res = 0x10000u | ovf_labels[off + i]; break; }
                 if (key > q) break;
             }
@@ -215,7 +235,7 @@ __device__ __forceinline__ bool part_find(const u32x4 v, uint32_t q, bool active
 #ifndef MC_NSLOT
 #define MC_NSLOT 2      // k-mers per lane per step (both probes in flight together)
 #endif
-template <int LINE>
+template <int LINE, bool WIDE>
 __global__ __launch_bounds__(BLOCK_THREADS, MC_MIN_WAVES)
 void query_kernel(const QueryArgs a)
 {
@@ -292,11 +312,12 @@ void query_kernel(const QueryArgs a)
                     constexpr int LPP = LINE / 16;        // lanes per probe
                     constexpr int PPR = 64 / LPP;         // probes per round
                     constexpr int NSLOT = MC_NSLOT;
-                    uint32_t q32[NSLOT], lidx[NSLOT];
+                    uint64_t qv[NSLOT];
+                    uint32_t lidx[NSLOT];
 #pragma unroll
                     for (int s = 0; s < NSLOT; s++) {
                         const uint32_t p = base + 64u * s + lane;
-                        q32[s] = 0; lidx[s] = LIDX_NONE;
+                        qv[s] = 0; lidx[s] = LIDX_NONE;
                         if (p < nk) {
                             // 80-bit window = containers j0..j0+4, first base in the top bits
                             const uint32_t j0 = first + (p >> 3);
@@ -312,21 +333,23 @@ void query_kernel(const QueryArgs a)
                             const uint64_t q  = div_u64(c, a.div);
                             const uint64_t r  = c - q * a.div.d;
                             if ((r >= a.shard_begin) && (r < a.shard_end)) {   // ref :1212-1214
-                                q32[s] = (uint32_t)q;
+                                qv[s] = q;
                                 lidx[s] = (uint32_t)(r - a.shard_begin);
                             }
                         }
                     }
                     // issue every line fetch of the step (2 slots x LPP rounds) before using any
                     const uint32_t part = lane & (LPP - 1);
-                    uint32_t gq[NSLOT][LPP], gl[NSLOT][LPP];
+                    uint64_t gq[NSLOT][LPP];
+                    uint32_t gl[NSLOT][LPP];
                     u32x4 gv[NSLOT][LPP];
 #pragma unroll
                     for (int s = 0; s < NSLOT; s++) {
 #pragma unroll
                         for (int j = 0; j < LPP; j++) {
                             const int src = j * PPR + (int)(lane / LPP);
-                            gq[s][j] = (uint32_t)__shfl((int)q32[s], src, 64);
+                            gq[s][j] = (uint32_t)__shfl((int)(uint32_t)qv[s], src, 64);
+                            if (WIDE) gq[s][j] |= (uint64_t)(uint32_t)__shfl((int)(uint32_t)(qv[s] >> 32), src, 64) << 32;
                             gl[s][j] = (uint32_t)__shfl((int)lidx[s], src, 64);
                             gv[s][j] = u32x4{0u, 0u, 0u, 0u};
                             if (gl[s][j] != LIDX_NONE) gv[s][j] = part_load<LINE>(a.lines, gl[s][j], part);
@@ -342,8 +365,8 @@ void query_kernel(const QueryArgs a)
 #pragma unroll
                         for (int j = 0; j < LPP; j++) {
                             uint32_t l = 0;
-                            const bool h = part_find<LINE>(gv[s][j], gq[s][j], gl[s][j] != LIDX_NONE, lane,
-                                                           a.ovf_keys, a.ovf_labels, l);
+                            const bool h = part_find<LINE, WIDE>(gv[s][j], gq[s][j], gl[s][j] != LIDX_NONE, lane,
+                                                                 a.ovf_keys, a.ovf_labels, l);
                             if (part == (uint32_t)j) { hit[s] = h; lab[s] = l; }
                         }
                     }
@@ -550,13 +573,13 @@ void block_sums_kernel(const uint8_t *sz, uint64_t n_buckets, uint32_t cap,
     if (threadIdx.x == 0) { blk_keys[blockIdx.x] = tk; blk_ovf[blockIdx.x] = to; }
 }
 
-template <int LINE>
+template <int LINE, bool WIDE>
 __global__ __launch_bounds__(RL_THREADS)
-void fill_lines_kernel(const uint8_t *sz, const uint32_t *keys, const uint16_t *labels,
+void fill_lines_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, const uint16_t *labels,
                        uint64_t n_buckets, const uint64_t *blk_key_off, const uint64_t *blk_ovf_off,
-                       uint8_t *lines, uint32_t *ovf_keys, uint16_t *ovf_labels)
+                       uint8_t *lines, typename KeyOf<WIDE>::type *ovf_keys, uint16_t *ovf_labels)
 {
-    using C = LineCfg<LINE>;
+    using C = LineCfg<LINE, WIDE>;
     __shared__ uint32_t s_a[RL_THREADS / 64], s_b[RL_THREADS / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
     uint32_t cnt[RL_PER_THREAD];
@@ -580,12 +603,14 @@ void fill_lines_kernel(const uint8_t *sz, const uint32_t *keys, const uint16_t *
 #pragma unroll
         for (int j = 0; j < C::DW; j++) dw[j] = 0;
 #pragma unroll
-        for (int j = 0; j < C::CAP; j++) dw[j] = KEY_SENTINEL;
+        for (int j = 0; j < C::CAP * C::KDW; j++) dw[j] = KEY_SENTINEL;
         if (c <= (uint32_t)C::CAP) {
 #pragma unroll
             for (int j = 0; j < C::CAP; j++) {
                 if ((uint32_t)j < c) {
-                    dw[j] = keys[koff + j];
+                    const uint64_t key = keys[koff + j];
+                    dw[j * C::KDW] = (uint32_t)key;
+                    if (WIDE) dw[j * C::KDW + C::KDW - 1] = (uint32_t)(key >> 32);
                     const uint32_t lab = labels[koff + j];
                     dw[C::LAB0 + (j >> 1)] |= (j & 1) ? (lab << 16) : lab;
                 }
@@ -608,11 +633,13 @@ void fill_lines_kernel(const uint8_t *sz, const uint32_t *keys, const uint16_t *
     }
 }
 
-// widen 16-bit keys (k <= 23 full / k <= 20 light databases, reference main.cc:255-263)
-__global__ void widen_keys_kernel(const uint16_t *in, uint64_t n, uint32_t *out)
+// widen file keys to the table's key width: 16-bit (k <= 23 full / k <= 20 light,
+// reference main.cc:255-263) or 32-bit to 32 / 64 bits
+template <typename IN, typename OUT>
+__global__ void widen_keys_kernel(const IN *in, uint64_t n, OUT *out)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (OUT)in[i];
 }
 
 } // namespace mc

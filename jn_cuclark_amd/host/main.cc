@@ -381,7 +381,6 @@ int main(int argc, char **argv)
     C.folder = o.folder;
     if (C.folder.back() != '/') C.folder.push_back('/');
     C.key_bytes = key_bytes_for((unsigned)o.k);
-    if (C.key_bytes == 8) die("k = 32 needs 8-byte keys: not supported by this build yet (k <= 31).", -1);
 #ifdef _OPENMP
     omp_set_num_threads((int)o.cpu);
 #endif

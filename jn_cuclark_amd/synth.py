@@ -88,7 +88,7 @@ def pack_uniform(codes2d):
 # --------------------------------------------------------------------------------
 # databases
 # --------------------------------------------------------------------------------
-def db_from_kmers(canon, labels, htsize):
+def db_from_kmers(canon, labels, htsize, wide=False):
     """(canonical k-mers, labels) -> the three on-disk arrays (.sz u8, .ky u32, .lb u16),
     buckets ascending, quotients ascending inside a bucket
     (reference src/hashTable_hh.hh:473-546)."""
@@ -101,9 +101,9 @@ def db_from_kmers(canon, labels, htsize):
     cnt = np.bincount(r.astype(np.int64), minlength=htsize)
     if cnt.max(initial=0) > 255:
         raise ValueError("bucket larger than 255")
-    if q.size and int(q.max()) >= 0xFFFFFFFF:
-        raise ValueError("quotients need more than 32 bits: raise htsize or lower k "
-                         "(reference main.cc:251-275 would pick 8-byte keys)")
+    kmax = int(q.max()) if q.size else 0
+    if kmax >= 0xFFFFFFFF or wide:       # the reference's 8-byte-key regime (main.cc:277-286)
+        return cnt.astype(np.uint8), q.astype(np.uint64), labels
     return cnt.astype(np.uint8), q.astype(np.uint32), labels
 
 
@@ -132,11 +132,11 @@ def toy_genomes(n_targets, length, seed, shared=0):
     return g
 
 
-def genome_db(genomes, k, htsize):
+def genome_db(genomes, k, htsize, wide=False):
     km = np.concatenate([kmers_of(g, k) for g in genomes])
     tg = np.concatenate([np.full(max(g.size - k + 1, 0), i, dtype=np.uint16) for i, g in enumerate(genomes)])
     canon, lab = discriminative(km, tg, k)
-    return db_from_kmers(canon, lab, htsize)
+    return db_from_kmers(canon, lab, htsize, wide=wide)
 
 
 def random_db(seed, htsize, n_keys, n_targets, k):

@@ -247,8 +247,6 @@ def test_batched_streaming_interface(gpu, oracle):
 def test_errors_are_reported_not_fatal(gpu):
     from jn_cuclark_amd import CuClarkDB, McError
     with pytest.raises(McError):
-        CuClarkDB(k=31, numBatches=1, numTargets=3, htsize=1000003)       # needs 8-byte keys
-    with pytest.raises(McError):
         CuClarkDB(k=40, numBatches=1, numTargets=3)
     with CuClarkDB(k=K, numBatches=1, numTargets=3, htsize=HT) as db:
         with pytest.raises(McError):
@@ -287,3 +285,26 @@ def test_two_byte_keys_and_sharded_file_load(gpu, oracle, tmp_path):
         assert db.read(base, key_bytes=2, shard=(a, b)) is True
         _, rows = db.classify(rp, con, extended=True)
     assert np.array_equal(rows, rows_want)
+
+
+@pytest.mark.parametrize("line", [64, 128])
+def test_wide_keys_k_and_table_size_beyond_32_bit_quotients(gpu, oracle, line, monkeypatch):
+    """the reference's T64 regime (k = 32 with the full table, main.cc:277-286): quotients
+    need 64 bits; here reached with k = 25 on a 100003-bucket table (4^25 / 100003 > 2^32)"""
+    k, ht = 25, 100003
+    genomes = synth.toy_genomes(6, 30000, seed=95, shared=400)
+    sz, ky, lb = synth.genome_db(genomes, k, ht)
+    assert ky.dtype == np.uint64 and ky.max() > 0xFFFFFFFF
+    names, seqs = mixed_fasta(genomes, k, seed=5, n=1500)
+    text = synth.fasta_text(names, seqs)
+    _, rp, con = pack_with_oracle(oracle, text, k)
+    want_rows, _ = oracle.OracleDB.from_arrays(ht, sz, ky, lb).query_rows(k, rp, con, 15)
+    monkeypatch.setenv("MC_LINE_BYTES", str(line))
+    with _open(gpu, sz, ky, lb, k=k, ht=ht, ntargets=6) as db:
+        info = db.db_info()
+        got, rows = db.classify(rp, con, extended=True)
+    assert info["line_bytes"] == line and info["line_capacity"] == (6 if line == 64 else 12)
+    assert info["n_overflow_buckets"] > 0 or line == 128
+    assert np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
+    assert (got[:, 2] > 0).sum() > 800

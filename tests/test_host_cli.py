@@ -224,3 +224,37 @@ def test_runs_under_the_reference_classify_script(tmp_path):
     else:
         assert "No HIP devices" in r.stderr
     os.remove(str(base) + ".sz")
+
+
+@pytest.mark.gpu
+def test_k32_full_table_end_to_end(oracle, tmp_path):
+    """k = 32: 8-byte keys on disk (reference T64, main.cc:277-286) and in HBM"""
+    _build()
+    k, ht = 32, 1610612741
+    genomes = synth.toy_genomes(3, 5000, seed=97, shared=300)
+    labels = ["A", "B", "C"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    names, seqs = mixed_fasta(genomes, k, seed=3, n=600)
+    text = synth.fasta_text(names, seqs)
+    p = tmp_path / "reads.fa"
+    p.write_bytes(text)
+    r = _run("cuCLARK", ["-k", "32", "-T", targets, "-D", str(dbdir), "-O", str(p), "-R", str(tmp_path / "res")])
+    assert r.returncode == 0, r.stderr
+    base = str(dbdir / ("db_central_k32_t3_s%d_m0.tsk" % ht))
+    n = os.path.getsize(base + ".lb") // 2
+    assert os.path.getsize(base + ".ky") == 8 * n
+    ns, ne, sp, ep, ln = oracle.index_reads(text)
+    rp, con = oracle.pack_reads(text, sp, ep, ln, k)
+    odb = oracle.OracleDB.load(base, ht, 8)
+    res, _ = odb.classify(k, rp, con, 15)
+    want = "Object_ID,Gamma,Assignment,Score,Confidence\n" + "".join(
+        oracle.csv_line(text[int(ns[i]):int(ne[i])], res[i], int(ln[i]), k, (["NA"] + labels)[int(res[i, 1])])
+        for i in range(ln.size))
+    assert open(str(tmp_path / "res.csv")).read() == want
+    assert (res[:, 2] > 0).sum() > 300
+    os.remove(base + ".sz")
