@@ -54,6 +54,8 @@ def main():
                     help="BASELINE.json configs[]: 3 = full table, k=31, 10M reads (default, the metric's "
                          "configuration); 2 = cuCLARK-l light table (~4 GB on disk), k=27, 1M reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true",
+                    help="N>1 replica runs also exercise the sharded RCCL path once, untimed; skip that")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
     ap.add_argument("--verify", type=int, default=20000, help="reads checked against the oracle (0 = none)")
     args = ap.parse_args()
@@ -199,7 +201,7 @@ def main():
                 "reads_assigned": round(assigned, 4), "reads_over_maxhits": st["reads_over_maxhits"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "mc::query_kernel<%d>" % info["line_bytes"],
+                "bound": "hbm", "kernel": "mc::query_kernel<%d, false>" % info["line_bytes"],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel_ms": round(kern_ms_avg, 4), "algorithmic_bytes_per_read": round(bytes_per_read, 1),
@@ -256,12 +258,64 @@ def main():
             odb.close()
         elif world == 1:
             out["cpu_baseline"] = None
+
+    if world > 1 and not shard_mode and not args.no_shard_check:
+        del d_sz, d_keys, d_labels
+        db.close()
+        torch.cuda.empty_cache()
+        chk = shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend)
+        if rank == 0:
+            out["shard_path"] = chk
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     db.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend):
+    """N > 1, outside the timed region: run the SHARDED path (table split by bucket range,
+    every rank sees every read, sparse rows reduce-scattered by read range over RCCL,
+    merge + top-2 on the owner) on a 12.8 GB table and check it, rank by rank, against the
+    unsharded result.  Returns a small dict for the JSON line; never raises."""
+    import time as _t
+    try:
+        from jn_cuclark_amd import CuClarkDB, synth_gpu
+        from jn_cuclark_amd.dist import ShardedClassifier, HipBackend, shard_range, read_range
+        k, ht, T, lam, n = 29, 200000033, 512, 3.75, 2_000_000
+        genomes = synth_gpu.make_genomes(T, 50_000, seed=41, device=dev)
+        rp, con = synth_gpu.make_reads(genomes, n, READ_LEN, seed=42)
+        full = synth_gpu.build_db(dev, 41, k, ht, T, lam, genomes=genomes)
+        with CuClarkDB(k=k, numBatches=1, numTargets=T, device=dev_index, htsize=ht, maxhits=15) as dbf:
+            dbf.read_device(*full)
+            want = torch.zeros((n, 5), dtype=torch.int16, device=dev)
+            dbf.query_device(rp, con, final_t=want, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        del full
+        sh = shard_range(ht, rank, world)
+        part = synth_gpu.build_db(dev, 41, k, ht, T, lam, genomes=genomes, shard=sh)
+        with CuClarkDB(k=k, numBatches=1, numTargets=T, device=dev_index, htsize=ht, maxhits=15) as dbs:
+            dbs.read_device(*part, shard=sh)
+            sc = ShardedClassifier(HipBackend(dbs, dev))
+            fin, (lo, hi) = sc.classify(rp, con, n)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(fin, want[lo:hi]))
+            dist.barrier()
+            t0 = _t.perf_counter()
+            steps = 5
+            for _ in range(steps):
+                sc.classify(rp, con, n)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = _t.perf_counter() - t0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return {"verified_equal_to_unsharded": bool(flag.item()), "Mreads_per_s": round(n * steps / dt / 1e6, 2),
+                "table": "HTSIZE=%d k=%d, %d shards, %d reads/step, all_to_all of %d-byte rows" % (ht, k, world, n, 2 * dbs.row_len)}
+    except Exception as e:      # the headline measurement must survive a failure here
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 if __name__ == "__main__":

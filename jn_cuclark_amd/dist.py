@@ -55,9 +55,16 @@ class ShardedClassifier:
         lo, hi, per = read_range(n_reads, self.rank, W)
         send = torch.zeros((W * per, L), dtype=torch.int16, device=rows.device)
         send[:n_reads] = rows[:n_reads]
-        recv = torch.empty_like(send)
         # bytes on the wire: neither RCCL nor gloo has a 16-bit integer type
-        dist.all_to_all_single(recv.view(torch.uint8).view(-1), send.view(torch.uint8).view(-1), group=self.group)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal on a box without RCCL peers: stage through the host
+            s8 = send.view(torch.uint8).view(-1).cpu()
+            r8 = torch.empty_like(s8)
+            dist.all_to_all_single(r8, s8, group=self.group)
+            recv = r8.to(send.device).view(torch.int16).view(W * per, L)
+        else:
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv.view(torch.uint8).view(-1), send.view(torch.uint8).view(-1), group=self.group)
         return recv.view(W, per, L), (lo, hi, per)
 
     def classify(self, reads_ptr, containers, n_reads):
