@@ -53,29 +53,6 @@ struct Slot {
     uint16_t *d_rows = nullptr;
 };
 
-// libdivide-style magic for unsigned 64-bit division by a run-time constant
-mc::DivU64 make_div(uint64_t d)
-{
-    mc::DivU64 r{};
-    r.d = d;
-    const uint32_t L = 63u - (uint32_t)__builtin_clzll(d);
-    if ((d & (d - 1)) == 0) { r.magic = 0; r.shift = L; r.add = 0; return r; }
-    const unsigned __int128 num = (unsigned __int128)1 << (64 + L);
-    uint64_t m = (uint64_t)(num / d);
-    const uint64_t rem = (uint64_t)(num % d);
-    const uint64_t e = d - rem;
-    if (e < ((uint64_t)1 << L)) {
-        r.shift = L; r.add = 0;
-    } else {
-        m += m;
-        const uint64_t twice = rem + rem;
-        if (twice >= d || twice < rem) m += 1;
-        r.shift = L; r.add = 1;
-    }
-    r.magic = m + 1;
-    return r;
-}
-
 } // namespace
 
 struct mc_ctx {
@@ -329,6 +306,8 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
 
 extern "C" {
 
+void mc_set_last_error_(const char *msg) { g_err = msg ? msg : ""; }     // for mc_build.hip
+
 const char *mc_last_error(void) { return g_err.c_str(); }
 int mc_api_version(void) { return MC_API_VERSION; }
 
@@ -358,7 +337,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     if (device >= n) return fail(MC_ENODEVICE, "device index out of range");
     mc_ctx *c = new mc_ctx();
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
-    c->div = make_div(htsize);
+    c->div = mc::make_div(htsize);
     c->wide = wide;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;

@@ -49,6 +49,29 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t n, const DivU64 &dv)
     return q >> dv.shift;
 }
 
+// host side: libdivide-style magic for unsigned 64-bit division by a run-time constant
+inline DivU64 make_div(uint64_t d)
+{
+    DivU64 r{};
+    r.d = d;
+    const uint32_t L = 63u - (uint32_t)__builtin_clzll(d);
+    if ((d & (d - 1)) == 0) { r.magic = 0; r.shift = L; r.add = 0; return r; }
+    const unsigned __int128 num = (unsigned __int128)1 << (64 + L);
+    uint64_t m = (uint64_t)(num / d);
+    const uint64_t rem = (uint64_t)(num % d);
+    const uint64_t e = d - rem;
+    if (e < ((uint64_t)1 << L)) {
+        r.shift = L; r.add = 0;
+    } else {
+        m += m;
+        const uint64_t twice = rem + rem;
+        if (twice >= d || twice < rem) m += 1;
+        r.shift = L; r.add = 1;
+    }
+    r.magic = m + 1;
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // bucket lines
 //   LINE bytes per bucket.  Narrow keys (quotient < 2^32-1: every k <= 31 of the
@@ -472,7 +495,7 @@ void query_kernel(const QueryArgs a)
 // merge / result (one thread per read), for the sharded path
 // ---------------------------------------------------------------------------
 // ref CuClarkDB.cu:1261-1355; keeps the maxhits smallest ids when the union is larger.
-__global__ void merge_rows_kernel(const uint16_t *A, const uint16_t *B, uint32_t row_len,
+static __global__ void merge_rows_kernel(const uint16_t *A, const uint16_t *B, uint32_t row_len,
                                   uint64_t n_reads, uint16_t *out)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,7 +520,7 @@ __global__ void merge_rows_kernel(const uint16_t *A, const uint16_t *B, uint32_t
 }
 
 // ref CuClarkDB.cu:1361-1411
-__global__ void result_rows_kernel(const uint16_t *rows, uint32_t row_len, uint64_t n_reads,
+static __global__ void result_rows_kernel(const uint16_t *rows, uint32_t row_len, uint64_t n_reads,
                                    uint16_t *out5)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,7 +546,7 @@ static constexpr int RL_PER_THREAD = 4;
 static constexpr int RL_BUCKETS = RL_THREADS * RL_PER_THREAD;   // buckets per workgroup
 
 // histogram of bucket sizes (256 bins) -- picks the line size
-__global__ void size_hist_kernel(const uint8_t *sz, uint64_t n_buckets, unsigned long long *hist)
+static __global__ void size_hist_kernel(const uint8_t *sz, uint64_t n_buckets, unsigned long long *hist)
 {
     __shared__ unsigned int h[256];
     h[threadIdx.x] = 0;
@@ -555,7 +578,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 
 // per workgroup of RL_BUCKETS buckets: number of keys, and number of keys living in
 // buckets larger than `cap`
-__global__ __launch_bounds__(RL_THREADS)
+static __global__ __launch_bounds__(RL_THREADS)
 void block_sums_kernel(const uint8_t *sz, uint64_t n_buckets, uint32_t cap,
                        uint32_t *blk_keys, uint32_t *blk_ovf)
 {

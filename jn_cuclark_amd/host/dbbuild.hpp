@@ -11,6 +11,8 @@
 #pragma once
 
 #include "common.hpp"
+#include "../../include/mc_api.h"
+#include "../../include/mc_build.h"
 
 #include <algorithm>
 #include <cstring>
@@ -84,12 +86,13 @@ inline std::string db_name(const std::string &folder, unsigned k, size_t n_label
 
 struct Occ { uint64_t r, q; uint16_t t; };
 
-// k-mers of one target file.  FASTA: every window of k valid bases (full variant,
-// :1127-1180), or -- light variant -- consecutive NON-overlapping windows of which
-// every gap-th is kept (:707-760).  Any non-ACGTU byte except '\n' resets the window;
-// '>' skips its header line.  FASTQ: the sequence line of each 4-line record.
-inline bool collect_file(const std::string &path, uint16_t target, unsigned k, unsigned gap,
-                         std::vector<Occ> &out, uint64_t &nt, std::string &err)
+// Forward k-mers of one target file, handed to emit(uint64_t).  FASTA: every window of k
+// valid bases (full variant, :1127-1180), or -- light variant -- consecutive
+// NON-overlapping windows of which every gap-th is kept (:707-760).  Any non-ACGTU byte
+// except '\n' resets the window; '>' skips its header line.  FASTQ: the sequence line of
+// each 4-line record.
+template <class Emit>
+inline bool scan_target_file(const std::string &path, unsigned k, unsigned gap, Emit &&emit, uint64_t &nt, std::string &err)
 {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) { err = "Failed to open " + path; return false; }
@@ -107,10 +110,6 @@ inline bool collect_file(const std::string &path, uint16_t target, unsigned k, u
     const auto &ct = codes();
     uint64_t km = 0, iter = 0;
     unsigned cpt = 0;
-    auto emit = [&](uint64_t x) {
-        const uint64_t c = canonical(x, k);
-        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target});
-    };
     size_t i = 0, n = buf.size();
     auto skip_line = [&]() { while (i < n && buf[i] != '\n') i++; i++; };
     if (fastq) skip_line();
@@ -142,6 +141,15 @@ inline bool collect_file(const std::string &path, uint16_t target, unsigned k, u
         nt++; km = 0; cpt = 0; i++;          // N and friends
     }
     return true;
+}
+
+inline bool collect_file(const std::string &path, uint16_t target, unsigned k, unsigned gap,
+                         std::vector<Occ> &out, uint64_t &nt, std::string &err)
+{
+    return scan_target_file(path, k, gap, [&](uint64_t x) {
+        const uint64_t c = canonical(x, k);
+        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target});
+    }, nt, err);
 }
 
 // Build and write <base>.sz/.ky/.lb.  Returns the number of stored k-mers.
@@ -200,4 +208,66 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
     return true;
 }
 
+// GPU build (include/mc_build.h): the host only extracts the k-mers, twice; counting,
+// scatter, per-bucket sort, the one-target rule and compaction run on the device.
+// Same files as build_database(), byte for byte (tests/test_host_cli.py).
+inline bool build_database_gpu(const Targets &T, unsigned k, unsigned gap, unsigned min_count, int key_bytes,
+                               const std::string &base, uint64_t &stored, std::string &err)
+{
+    mc_builder *B = nullptr;
+    if (mc_builder_open(&B, 0, k, HTSIZE) != 0) { err = mc_last_error(); return false; }
+    const size_t CHUNK = 1u << 23;
+    uint64_t nt = 0;
+    bool ok = true;
+    for (int pass = 0; pass < 2 && ok; pass++) {
+        if (pass == 1 && mc_builder_begin_fill(B) != 0) { err = mc_last_error(); ok = false; break; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) reduction(+ : nt)
+#endif
+        for (long t = 0; t < (long)T.files.size(); t++) {
+            if (!ok) continue;
+            const auto it = std::find(T.labels.begin(), T.labels.end(), T.files[t].second);
+            const uint16_t id = (uint16_t)(it - T.labels.begin());
+            std::vector<uint64_t> km; std::vector<uint16_t> tg;
+            km.reserve(CHUNK); tg.reserve(CHUNK);
+            std::string lerr;
+            uint64_t lnt = 0;
+            auto flush = [&]() {
+                if (km.empty()) return;
+#ifdef _OPENMP
+#pragma omp critical(mc_builder_feed)
+#endif
+                {
+                    const int rc = pass == 0 ? mc_builder_count(B, km.data(), km.size())
+                                             : mc_builder_fill(B, km.data(), tg.data(), km.size());
+                    if (rc != 0) { err = mc_last_error(); ok = false; }
+                }
+                km.clear(); tg.clear();
+            };
+            if (!scan_target_file(T.files[t].first, k, gap, [&](uint64_t x) {
+                    km.push_back(x); tg.push_back(id);
+                    if (km.size() >= CHUNK) flush();
+                }, lnt, lerr)) {
+#ifdef _OPENMP
+#pragma omp critical(mc_builder_feed)
+#endif
+                { err = lerr; ok = false; }
+            }
+            flush();
+            if (pass == 0) nt += lnt;
+        }
+    }
+    uint64_t distinct = 0;
+    if (ok && mc_builder_finish(B, min_count, &distinct, &stored) != 0) { err = mc_last_error(); ok = false; }
+    if (ok && mc_builder_write(B, base.c_str(), key_bytes) != 0) { err = mc_last_error(); ok = false; }
+    mc_builder_close(B);
+    if (ok) {
+        std::fprintf(stderr, "%lu nt read in total.\n", (unsigned long)nt);
+        std::fprintf(stderr, "Mother Hashtable successfully built. %lu %u-mers stored.\n", (unsigned long)distinct, k);
+        std::fprintf(stderr, "%lu %u-mers successfully stored in database.\n", (unsigned long)stored, k);
+    }
+    return ok;
+}
+
 } // namespace host
+

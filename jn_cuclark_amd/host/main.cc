@@ -72,6 +72,7 @@ struct Options {
     bool ext = false, verbose = false, tsk = false;
     const char *targets = nullptr, *folder = nullptr, *objects = nullptr, *objects2 = nullptr, *results = nullptr;
     const char *dump = nullptr;      // test hook: write the packed batches here
+    bool gpu_build = false;          // --gpu-build / MC_GPU_BUILD=1: build a missing database on the GPU
 };
 
 struct Classifier {
@@ -109,7 +110,10 @@ struct Classifier {
         uint64_t stored = 0;
         std::string err;
         std::cerr << "Creating database in disk..." << std::endl;
-        if (!build_database(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err)) die(err, -1);
+        const bool okb = opt.gpu_build
+            ? build_database_gpu(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err)
+            : build_database(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err);
+        if (!okb) die(err, -1);
     }
 
     void load()
@@ -367,6 +371,7 @@ int main(int argc, char **argv)
         if (val == "-d") { o.devices = (size_t)atoi(need("Please specify the number of devices to use!")); if (o.devices < 1) die("The number of devices should be higher than 0."); continue; }
         if (val == "--verbose") { o.verbose = true; continue; }
         if (val == "--dump-batches") { o.dump = need("--dump-batches needs a file"); continue; }
+        if (val == "--gpu-build") { o.gpu_build = true; continue; }
         die("Failed to recognize option: " + val);
     }
     // reference src/main.cc:214-228
@@ -384,6 +389,7 @@ int main(int argc, char **argv)
 #ifdef _OPENMP
     omp_set_num_threads((int)o.cpu);
 #endif
+    if (const char *e = getenv("MC_GPU_BUILD")) o.gpu_build = o.gpu_build || atoi(e) != 0;
     std::string err;
     if (!read_targets(o.targets, C.T, err)) die(err, -1);
     C.build_if_missing();

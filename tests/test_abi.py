@@ -32,6 +32,20 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load_library().mc_api_version() == 1
 
 
+def test_builder_symbols_exported():
+    txt = open(os.path.join(ROOT, "include", "mc_build.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mc_builder_[a-z_0-9]+)\s*\(", txt)))
+    assert len(names) == 7
+    from jn_cuclark_amd import _lib
+    if not os.path.exists(_lib.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.library_path())
+    for n in names:
+        assert hasattr(lib, n), n
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "jn_cuclark_amd")
     for dp, _, files in os.walk(pkg):

@@ -258,3 +258,40 @@ def test_k32_full_table_end_to_end(oracle, tmp_path):
     assert open(str(tmp_path / "res.csv")).read() == want
     assert (res[:, 2] > 0).sum() > 300
     os.remove(base + ".sz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_gpu_database_build_is_byte_identical_to_cpu_build(tmp_path, variant):
+    """--gpu-build (include/mc_build.h: count -> scan -> scatter -> per-bucket sort ->
+    one-target rule -> compact, on the device) writes the same three files as the CPU
+    builder, which tests/test_ref_host.py pins against the reference's own builder."""
+    import filecmp
+    _build()
+    light = variant == "light"
+    k = 27 if light else 31
+    ht = 57777779 if light else 1610612741
+    genomes = synth.toy_genomes(6, 60000, seed=33, shared=3000)
+    genomes[4] = genomes[4].copy()
+    genomes[4][10000:20000] = genomes[4][30000:40000]          # repeats inside one target
+    genomes[5] = genomes[5].copy()
+    genomes[5][:5000] = 3                                      # poly-A: one k-mer thousands of times
+    labels = ["a", "b", "c", "a", "d", "e"]
+    targets = _write_targets(tmp_path, genomes, labels)
+    reads = tmp_path / "reads.fa"
+    reads.write_bytes(synth.fasta_text([b"r0"], [synth.codes_to_ascii(genomes[0][:150])]))
+    exe = "cuCLARK-l" if light else "cuCLARK"
+    name = "db_central_k%d_t5_s%d_m0%s.tsk" % (k, ht, "_light_4" if light else "")
+    dirs = {}
+    for tag, extra in (("cpu", []), ("gpu", ["--gpu-build", "-n", "4"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = _run(exe, ["-k", str(k), "-T", targets, "-D", str(d), "-O", str(reads), "-R", str(tmp_path / ("o" + tag))] + extra)
+        assert r.returncode == 0, r.stderr
+        dirs[tag] = d
+    for ext in (".sz", ".ky", ".lb"):
+        a, b = str(dirs["cpu"] / (name + ext)), str(dirs["gpu"] / (name + ext))
+        assert os.path.getsize(a) > 0 and filecmp.cmp(a, b, shallow=False), ext
+    assert open(str(tmp_path / "ocpu.csv")).read() == open(str(tmp_path / "ogpu.csv")).read()
+    for d in dirs.values():
+        os.remove(str(d / (name + ".sz")))
