@@ -6,6 +6,7 @@
 // that needs one fails with MC_ENODEVICE / MC_EHIP.
 #include "../../include/mc_api.h"
 #include "mc_device.hpp"
+#include "mc_minimizer.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -73,6 +74,11 @@ struct mc_ctx {
     mc_db_info info{};
     int grid_blocks = 0;
 
+    // optional locality-aware index (mc_minimizer.hpp), selected with MC_INDEX=minimizer
+    int index_mode = 0;                // 0 = bucket lines, 1 = minimizer lines
+    uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
+    uint32_t mz_n_lines = 0, mz_m = 0;
+
     unsigned long long *d_over = nullptr;
 
     // batches
@@ -97,7 +103,10 @@ void free_db(mc_ctx *c)
     if (c->d_lines) (void)hipFree(c->d_lines);
     if (c->d_ovf_keys) (void)hipFree(c->d_ovf_keys);
     if (c->d_ovf_labels) (void)hipFree(c->d_ovf_labels);
+    if (c->d_mz_lines) (void)hipFree(c->d_mz_lines);
+    if (c->d_mz_extra) (void)hipFree(c->d_mz_extra);
     c->d_lines = nullptr; c->d_ovf_keys = nullptr; c->d_ovf_labels = nullptr;
+    c->d_mz_lines = nullptr; c->d_mz_extra = nullptr;
     c->db_loaded = false;
 }
 
@@ -120,11 +129,133 @@ int query_occupancy(int &occ)
     return MC_OK;
 }
 
+// exclusive u32 scan on the device (per-workgroup sums scanned on the host); *total = sum
+int scan_u32_device(mc_ctx *c, const uint32_t *d_v, uint64_t n, uint32_t *d_out, uint64_t *total)
+{
+    hipStream_t st = c->streams[0];
+    const uint32_t nblk = (uint32_t)((n + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    unsigned long long *d_blk = nullptr; uint64_t *d_boff = nullptr;
+    HIPCHK(hipMalloc(&d_blk, (size_t)nblk * 8));
+    HIPCHK(hipMalloc(&d_boff, (size_t)nblk * 8));
+    hipLaunchKernelGGL(mc::mz::mz_blocksum_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_v, n, d_blk);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> blk(nblk);
+    HIPCHK(hipMemcpyAsync(blk.data(), d_blk, (size_t)nblk * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> boff(nblk);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < nblk; i++) { boff[i] = acc; acc += blk[i]; }
+    if (acc >= 0xFFFFFFFFull) return fail(MC_EINVAL, "minimizer index: more than 2^32 extra lines");
+    HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mc::mz::mz_scan_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_v, n, d_boff, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_blk); (void)hipFree(d_boff);
+    *total = acc;
+    return MC_OK;
+}
+
+template <bool WIDE>
+int mz_build_passes(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels, uint64_t nb,
+                    uint64_t shard_begin, const uint64_t *d_koff, uint32_t nblk, uint32_t n_lines,
+                    uint32_t *d_count, uint32_t *d_cursor, uint32_t *d_extra, uint32_t *d_ebase, uint64_t *n_extra)
+{
+    typedef typename mc::KeyOf<WIDE>::type key_t;
+    hipStream_t st = c->streams[0];
+    hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                       static_cast<const key_t *>(d_keys), d_labels, nb, shard_begin, c->htsize, d_koff, c->k, c->mz_m,
+                       n_lines, d_count, d_cursor, (const uint32_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr);
+    HIPCHK(hipGetLastError());
+    const int g = (int)std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, 16384);
+    hipLaunchKernelGGL(mc::mz::mz_extra_count_kernel, dim3(g), dim3(256), 0, st, d_count, n_lines, d_extra);
+    HIPCHK(hipGetLastError());
+    int rc = scan_u32_device(c, d_extra, n_lines, d_ebase, n_extra);
+    if (rc) return rc;
+    const size_t ebytes = (size_t)(*n_extra ? *n_extra : 1) * mc::mz::MZ_LINE;
+    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess) return fail(MC_ENOMEM, "minimizer index: extra lines");
+    HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
+    hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                       static_cast<const key_t *>(d_keys), d_labels, nb, shard_begin, c->htsize, d_koff, c->k, c->mz_m,
+                       n_lines, d_count, d_cursor, d_ebase, c->d_mz_lines, c->d_mz_extra);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(g), dim3(256), 0, st, d_count, d_ebase, n_lines, c->d_mz_lines);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return MC_OK;
+}
+
+// Build the minimizer index (mc_minimizer.hpp) from the same raw arrays.
+int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
+                uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
+{
+    const uint64_t nb = shard_end - shard_begin;
+    hipStream_t st = c->streams[0];
+    const uint32_t nblk = (uint32_t)((nb + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    uint32_t *d_bk = nullptr, *d_bo = nullptr;
+    HIPCHK(hipMalloc(&d_bk, (size_t)nblk * 4));
+    HIPCHK(hipMalloc(&d_bo, (size_t)nblk * 4));
+    hipLaunchKernelGGL(mc::block_sums_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz, nb, 255u, d_bk, d_bo);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> bk(nblk);
+    HIPCHK(hipMemcpyAsync(bk.data(), d_bk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d_bk); (void)hipFree(d_bo);
+    std::vector<uint64_t> koff(nblk);
+    uint64_t ak = 0;
+    for (uint32_t i = 0; i < nblk; i++) { koff[i] = ak; ak += bk[i]; }
+    if (ak != n_keys) return fail(MC_EINVAL, "bucket sizes do not sum to n_keys");
+    uint64_t *d_koff = nullptr;
+    HIPCHK(hipMalloc(&d_koff, (size_t)nblk * 8));
+    HIPCHK(hipMemcpyAsync(d_koff, koff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+
+    free_db(c);
+    double per_line = 6.0;
+    if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 12.0) per_line = v; }
+    const uint64_t want = (uint64_t)((double)n_keys / per_line) + 1024;
+    if (want >= 0xFFFFFFF0ull) return fail(MC_EINVAL, "minimizer index: too many lines");
+    const uint32_t n_lines = (uint32_t)want;
+    c->mz_n_lines = n_lines;
+    c->mz_m = mc::mz::mmer_len(c->k);
+    uint32_t *d_count = nullptr, *d_cursor = nullptr, *d_extra = nullptr, *d_ebase = nullptr;
+    HIPCHK(hipMalloc(&d_count, (size_t)n_lines * 4));
+    HIPCHK(hipMalloc(&d_cursor, (size_t)n_lines * 4));
+    HIPCHK(hipMalloc(&d_extra, (size_t)n_lines * 4));
+    HIPCHK(hipMalloc(&d_ebase, (size_t)n_lines * 4));
+    HIPCHK(hipMemsetAsync(d_count, 0, (size_t)n_lines * 4, st));
+    HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)n_lines * 4, st));
+    const size_t lbytes = (size_t)n_lines * mc::mz::MZ_LINE;
+    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess)
+        return fail(MC_ENOMEM, "hipMalloc of " + std::to_string(lbytes) + " bytes of minimizer lines failed");
+    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, st));
+    uint64_t n_extra = 0;
+    int rc = c->wide ? mz_build_passes<true>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra)
+                     : mz_build_passes<false>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra);
+    (void)hipFree(d_count); (void)hipFree(d_cursor); (void)hipFree(d_extra); (void)hipFree(d_ebase); (void)hipFree(d_koff);
+    if (rc) return rc;
+    c->info.htsize = c->htsize;
+    c->info.shard_begin = shard_begin; c->info.shard_end = shard_end;
+    c->info.n_keys = n_keys;
+    c->info.n_overflow_buckets = n_extra;            // extra lines
+    c->info.n_overflow_keys = 0;
+    c->info.line_bytes = mc::mz::MZ_LINE;
+    c->info.line_capacity = mc::mz::MZ_CAP;
+    c->info.device_bytes = lbytes + n_extra * mc::mz::MZ_LINE;
+    int occ = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::mz::mz_query_kernel, mc::BLOCK_THREADS, 0));
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+    if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
+    c->grid_blocks = occ * c->n_cu;
+    c->db_loaded = true;
+    return MC_OK;
+}
+
 // Build the bucket lines from raw arrays resident on the device; d_keys holds u32
 // quotients, or u64 when the context is in wide-key mode.
 int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
              uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
 {
+    if (c->index_mode == 1 && c->k >= 16) return relayout_mz(c, d_sz, d_keys, d_labels, n_keys, shard_begin, shard_end);
     const uint64_t nb = shard_end - shard_begin;
     hipStream_t st = c->streams[0];
 
@@ -289,7 +420,12 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     const uint64_t want = (n_groups + mc::WAVES_PER_BLOCK - 1) / mc::WAVES_PER_BLOCK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->grid_blocks);
     const dim3 g(grid), b(mc::BLOCK_THREADS);
-    if (!c->wide) {
+    if (c->d_mz_lines) {
+        mc::mz::MzArgs m{};
+        m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra; m.n_lines = c->mz_n_lines; m.m = c->mz_m;
+        m.sharded = (c->info.shard_begin != 0 || c->info.shard_end != c->htsize) ? 1u : 0u;
+        hipLaunchKernelGGL(mc::mz::mz_query_kernel, g, b, 0, st, m);
+    } else if (!c->wide) {
         if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, false>), g, b, 0, st, a);
         else                          hipLaunchKernelGGL((mc::query_kernel<128, false>), g, b, 0, st, a);
     } else {
@@ -339,6 +475,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
     c->div = mc::make_div(htsize);
     c->wide = wide;
+    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "minimizer") == 0 ? 1 : 0;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);

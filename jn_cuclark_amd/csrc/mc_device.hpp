@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mc {
 
@@ -135,21 +136,39 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, uint32_t k)
     return r >> (64u - 2u * k);
 }
 
+// Wave-wide reductions on DPP (no LDS crossbar round trips): xor butterflies inside each
+// row of 16 lanes, then row_bcast15 / row_bcast31 carry the row results upward; lane 63
+// ends with the total, which v_readlane broadcasts.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t uniform_lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)uniform_lane));
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    uint32_t w;
+    w = dpp_zero_u32<0xB1, 0xF>(v);  v = w > v ? w : v;      // quad_perm [1,0,3,2]
+    w = dpp_zero_u32<0x4E, 0xF>(v);  v = w > v ? w : v;      // quad_perm [2,3,0,1]
+    w = dpp_zero_u32<0x141, 0xF>(v); v = w > v ? w : v;      // row_half_mirror
+    w = dpp_zero_u32<0x140, 0xF>(v); v = w > v ? w : v;      // row_mirror
+    w = dpp_zero_u32<0x142, 0xA>(v); v = w > v ? w : v;      // row_bcast15 -> rows 1, 3
+    w = dpp_zero_u32<0x143, 0xC>(v); v = w > v ? w : v;      // row_bcast31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return v;
+    v += dpp_zero_u32<0xB1, 0xF>(v);
+    v += dpp_zero_u32<0x4E, 0xF>(v);
+    v += dpp_zero_u32<0x141, 0xF>(v);
+    v += dpp_zero_u32<0x140, 0xF>(v);
+    v += dpp_zero_u32<0x142, 0xA>(v);
+    v += dpp_zero_u32<0x143, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ---------------------------------------------------------------------------
@@ -282,7 +301,7 @@ void query_kernel(const QueryArgs a)
         uint32_t ptr_v = 0;
         if (lane <= nr) ptr_v = a.reads_ptr[r0 + lane];
         const uint32_t c0 = __builtin_amdgcn_readlane(ptr_v, 0);
-        const uint32_t c1 = __shfl(ptr_v, nr, 64);
+        const uint32_t c1 = lane_bcast(ptr_v, nr);
         const uint32_t c0a = c0 & ~7u;
 
         // stage [c0a, c1) into this wave's LDS slice (16-byte loads, coalesced)
@@ -305,18 +324,23 @@ void query_kernel(const QueryArgs a)
 
         // container i of the batch (absolute index); every access is clamped so that
         // malformed input can only produce wrong counts, never an out-of-range access
+        // (two instantiations of the per-group body, so that container reads compile to plain
+        // LDS reads or plain global reads -- a run-time select would make them FLAT loads)
+        auto run_group = [&](auto staged_c) {
+        constexpr bool STAGED = decltype(staged_c)::value;
         auto con = [&](uint32_t i) -> uint32_t {
-            if (staged) {
+            if constexpr (STAGED) {
                 const uint32_t li = i - c0a;
                 return slice[li < (uint32_t)(STAGE_CON + 15) ? li : (uint32_t)(STAGE_CON + 15)];
+            } else {
+                const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
+                return a.containers[ii];
             }
-            const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
-            return a.containers[ii];
         };
 
         for (uint32_t ri = 0; ri < nr; ri++) {
-            const uint32_t beg = (uint32_t)__shfl((int)ptr_v, (int)ri, 64);
-            uint32_t end = (uint32_t)__shfl((int)ptr_v, (int)ri + 1, 64);
+            const uint32_t beg = lane_bcast(ptr_v, ri);
+            uint32_t end = lane_bcast(ptr_v, ri + 1u);
             if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
 
             // accumulator: lane j = j-th distinct target of this read
@@ -406,7 +430,7 @@ void query_kernel(const QueryArgs a)
 #pragma unroll
                         for (int s = 0; s < NSLOT; s++) {
                             if (!got && m[s]) {
-                                t = (uint32_t)__shfl((int)lab[s], __ffsll((unsigned long long)m[s]) - 1, 64);
+                                t = lane_bcast(lab[s], (uint32_t)(__ffsll((unsigned long long)m[s]) - 1));
                                 got = true;
                             }
                         }
@@ -446,7 +470,7 @@ void query_kernel(const QueryArgs a)
             const bool need_rank = (a.flags & 2u) || (n_acc > a.maxhits);
             if (need_rank) {
                 for (uint32_t j = 0; j < n_acc; j++) {
-                    const uint32_t tj = (uint32_t)__shfl((int)acc_t, (int)j, 64);
+                    const uint32_t tj = lane_bcast(acc_t, j);
                     rank += (tj < acc_t) ? 1u : 0u;
                 }
                 if (n_acc > a.maxhits) {
@@ -485,6 +509,8 @@ void query_kernel(const QueryArgs a)
                 if (lane < 5u) a.final_rows[rd * 5u + lane] = (uint16_t)out;
             }
         }
+        };   // run_group
+        if (staged) run_group(std::true_type{}); else run_group(std::false_type{});
         // the slice is rewritten by the next group: keep the compiler from hoisting
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,484 @@
+// mc_minimizer.hpp -- locality-aware index: the same database, bucketed by MINIMIZER.
+//
+// Why.  With the bucket-line table (mc_device.hpp) every k-mer of a read is one random
+// HBM request, and the kernel sits on the memory system's random-request ceiling
+// (~50 G requests/s).  Consecutive k-mers of a read overlap in k-1 bases;
+// k-mers that share their minimizer (the smallest, under a fixed hash, of the canonical
+// m-mers inside the k-mer) can share a bucket.  A 150 bp read has 120 k-mers but only
+// ~2*120/(k-m+2) distinct minimizers, so it needs ~17 line fetches instead of 120.
+//
+// What stays the same.  The on-disk database, the batch format, and the answer: a k-mer
+// hits iff its canonical value is a stored k-mer, with that k-mer's label.  Only the
+// in-HBM arrangement differs, built once at load from the same arrays:
+//
+//   K(c)    = min over the k-m+1 windows w of canonical k-mer c of hash32(min(w, rc(w)))
+//             (orientation-free: x and rc(x) have the same set of canonical m-mers)
+//   line(c) = mulhi(mix32(K(c)), n_lines)
+//   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
+//             12 labels (u16), dword30 = count | extra_lines<<8, dword31 = first extra line
+//   extra lines (same shape) hold what does not fit; they are contiguous per line.
+//
+// Lookup is exact: the stored key is the whole canonical k-mer.
+#pragma once
+
+#include "mc_device.hpp"
+
+namespace mc {
+namespace mz {
+
+static constexpr int MZ_LINE = 128;
+static constexpr int MZ_CAP = 12;
+static constexpr int MZ_MAXW = 13;            // windows per k-mer: w = k - m + 1 <= 13
+#ifndef MC_MZ_NS
+#define MC_MZ_NS 2
+#endif
+static constexpr int MZ_NS = MC_MZ_NS;        // 64-k-mer slots per step (a 150 bp read = one step of 2)
+static constexpr int MZ_RUNS = 16 * MZ_NS;    // runs (distinct lines) fetched per batch
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+// minimizer length for a k-mer length (w = k - m + 1 windows, at most MZ_MAXW)
+__host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
+
+// 32-bit ordering hash of a canonical m-mer.  The minimizer KEY of a k-mer is the smallest
+// such hash over its windows; lines are addressed by that value, so two m-mers with equal
+// hashes merely share a line -- no tie-break is needed and x / rc(x) agree by construction.
+__device__ __forceinline__ uint32_t mmer_key(uint64_t w, uint32_t m)
+{
+    const uint64_t rc = revcomp(w, m);
+    const uint64_t z = (w < rc ? w : rc) * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(z >> 32) ^ (uint32_t)z;
+}
+
+// K(c) for a stored canonical k-mer (index build)
+__device__ __forceinline__ uint32_t kmer_min_key(uint64_t c, uint32_t k, uint32_t m)
+{
+    const uint64_t mmask = (1ull << (2 * m)) - 1ull;
+    uint32_t best = ~0u;
+    for (uint32_t i = 0; i + m <= k; i++) {
+        const uint32_t key = mmer_key((c >> (2 * (k - m - i))) & mmask, m);
+        best = key < best ? key : best;
+    }
+    return best;
+}
+
+__device__ __forceinline__ uint32_t line_of(uint32_t K, uint32_t n_lines)
+{
+    uint32_t h = K * 0x85EBCA6Bu;
+    h ^= h >> 15; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return __umulhi(h, n_lines);
+}
+
+// ---------------------------------------------------------------------------
+// index build from the raw bucket arrays (sizes u8, quotients, labels)
+// ---------------------------------------------------------------------------
+// PASS 0: count k-mers per line.  PASS 1: place them.
+template <int PASS, bool WIDE>
+__global__ __launch_bounds__(RL_THREADS)
+void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, const uint16_t *labels,
+                     uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const uint64_t *blk_key_off,
+                     uint32_t k, uint32_t m, uint32_t n_lines,
+                     uint32_t *count, uint32_t *cursor, const uint32_t *extra_base,
+                     uint8_t *lines, uint8_t *extra_lines)
+{
+    __shared__ uint32_t s_a[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    uint32_t cnt[RL_PER_THREAD], ksum = 0;
+#pragma unroll
+    for (int i = 0; i < RL_PER_THREAD; i++) { cnt[i] = (b0 + i < n_buckets) ? sz[b0 + i] : 0u; ksum += cnt[i]; }
+    uint32_t tk;
+    uint64_t koff = blk_key_off[blockIdx.x] + block_exclusive_scan(ksum, s_a, tk);
+    for (int i = 0; i < RL_PER_THREAD; i++) {
+        const uint64_t b = b0 + i;
+        if (b >= n_buckets) break;
+        for (uint32_t j = 0; j < cnt[i]; j++) {
+            const uint64_t c = (uint64_t)keys[koff + j] * htsize + (bucket0 + b);     // the canonical k-mer
+            const uint32_t l = line_of(kmer_min_key(c, k, m), n_lines);
+            if (PASS == 0) {
+                atomicAdd(&count[l], 1u);
+            } else {
+                const uint32_t slot = atomicAdd(&cursor[l], 1u);
+                uint8_t *base;
+                uint32_t pos;
+                if (slot < (uint32_t)MZ_CAP) { base = lines + (uint64_t)l * MZ_LINE; pos = slot; }
+                else {
+                    const uint32_t e = slot - MZ_CAP;
+                    base = extra_lines + ((uint64_t)extra_base[l] + e / MZ_CAP) * MZ_LINE;
+                    pos = e % MZ_CAP;
+                }
+                reinterpret_cast<uint64_t *>(base)[pos] = c;
+                reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[pos] = labels[koff + j];
+            }
+        }
+        koff += cnt[i];
+    }
+}
+
+// number of extra lines per line (for the scan) and, later, the headers
+__global__ void mz_extra_count_kernel(const uint32_t *count, uint32_t n_lines, uint32_t *extra)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
+        const uint32_t c = count[i];
+        extra[i] = c > (uint32_t)MZ_CAP ? (c - MZ_CAP + MZ_CAP - 1) / MZ_CAP : 0u;
+    }
+}
+
+__global__ void mz_header_kernel(const uint32_t *count, const uint32_t *extra_base, uint32_t n_lines, uint8_t *lines)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
+        const uint32_t c = count[i];
+        const uint32_t ex = c > (uint32_t)MZ_CAP ? (c - MZ_CAP + MZ_CAP - 1) / MZ_CAP : 0u;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(lines + i * MZ_LINE) + 30;
+        hdr[0] = (c < (uint32_t)MZ_CAP ? c : (uint32_t)MZ_CAP) | (ex << 8);
+        hdr[1] = extra_base[i];
+    }
+}
+
+// exclusive scan of u32 -> u32 (per-workgroup sums scanned on the host)
+static __global__ __launch_bounds__(RL_THREADS)
+void mz_blocksum_kernel(const uint32_t *v, uint64_t n, unsigned long long *blk)
+{
+    __shared__ unsigned long long s[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    unsigned long long sum = 0;
+    for (int i = 0; i < RL_PER_THREAD; i++) if (b0 + i < n) sum += v[b0 + i];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < RL_THREADS / 64; w++) t += s[w]; blk[blockIdx.x] = t; }
+}
+
+static __global__ __launch_bounds__(RL_THREADS)
+void mz_scan_kernel(const uint32_t *v, uint64_t n, const uint64_t *blk_off, uint32_t *out)
+{
+    __shared__ uint32_t s_a[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    uint32_t c[RL_PER_THREAD], sum = 0;
+    for (int i = 0; i < RL_PER_THREAD; i++) { c[i] = (b0 + i < n) ? v[b0 + i] : 0u; sum += c[i]; }
+    uint32_t tot;
+    uint64_t o = blk_off[blockIdx.x] + block_exclusive_scan(sum, s_a, tot);
+    for (int i = 0; i < RL_PER_THREAD; i++) { if (b0 + i < n) out[b0 + i] = (uint32_t)o; o += c[i]; }
+}
+
+// ---------------------------------------------------------------------------
+// query
+// ---------------------------------------------------------------------------
+struct MzArgs {
+    QueryArgs q;               // reads, outputs, shard range, div, k, maxhits, flags (lines unused)
+    const uint8_t *lines;      // n_lines primary lines
+    const uint8_t *extra;      // extra lines
+    uint32_t n_lines;
+    uint32_t m;
+    uint32_t sharded;          // apply the bucket-range filter (r = c % HTSIZE in [shard_begin, shard_end))
+};
+
+__device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, uint32_t &label)
+{
+    const uint64_t *keys = reinterpret_cast<const uint64_t *>(line);
+    bool hit = false;
+#pragma unroll
+    for (int e = 0; e < MZ_CAP; e++)
+        if (keys[e] == c) { hit = true; label = reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[e]; }
+    return hit;
+}
+
+#ifndef MC_MZ_MIN_WAVES
+#define MC_MZ_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(BLOCK_THREADS, MC_MZ_MIN_WAVES)
+void mz_query_kernel(const MzArgs A)
+{
+    const QueryArgs &a = A.q;
+    __shared__ __attribute__((aligned(16))) uint16_t s_con[WAVES_PER_BLOCK][STAGE_CON + 16];
+    __shared__ uint32_t s_key[WAVES_PER_BLOCK][64 * MZ_NS + MZ_MAXW + 3];
+    __shared__ uint32_t s_runline[WAVES_PER_BLOCK][MZ_RUNS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_line[WAVES_PER_BLOCK][MZ_RUNS * MZ_LINE];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint16_t *slice = s_con[wave];
+    uint32_t *keyv = s_key[wave];
+    uint32_t *runline = s_runline[wave];
+    uint8_t *linebuf = s_line[wave];
+
+    const uint32_t k = a.k, m = A.m;
+    const uint32_t W = k - m + 1;
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
+    const uint64_t mmask = (1ull << (2u * m)) - 1ull;
+    const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
+    const uint64_t gstride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t row_len = 2u * a.maxhits + 2u;
+
+    for (uint64_t g = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; g < n_groups; g += gstride) {
+        const uint64_t r0 = g * GROUP_READS;
+        const uint32_t nr = (uint32_t)((a.n_reads - r0) < GROUP_READS ? (a.n_reads - r0) : GROUP_READS);
+        uint32_t ptr_v = 0;
+        if (lane <= nr) ptr_v = a.reads_ptr[r0 + lane];
+        const uint32_t c0 = __builtin_amdgcn_readlane(ptr_v, 0);
+        const uint32_t c1 = lane_bcast(ptr_v, nr);
+        const uint32_t c0a = c0 & ~7u;
+        const bool staged = a.stage_ok && (c1 - c0a) <= (uint32_t)STAGE_CON;
+        if (staged) {
+            for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
+                const uint64_t gi = (uint64_t)c0a + j;
+                if (gi + 8u <= a.n_containers) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(a.containers + gi);
+                    *reinterpret_cast<uint4 *>(slice + j) = v;
+                } else {
+                    for (uint32_t t = 0; t < 8u; t++)
+                        slice[j + t] = (gi + t < a.n_containers) ? a.containers[gi + t] : (uint16_t)0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto run_group = [&](auto staged_c) {
+        constexpr bool STAGED = decltype(staged_c)::value;
+        auto con = [&](uint32_t i) -> uint32_t {
+            if constexpr (STAGED) {
+                const uint32_t li = i - c0a;
+                return slice[li < (uint32_t)(STAGE_CON + 15) ? li : (uint32_t)(STAGE_CON + 15)];
+            } else {
+                const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
+                return a.containers[ii];
+            }
+        };
+        // `len` bases starting at base position p of the part whose containers start at `first`
+        auto bases_at = [&](uint32_t first, uint32_t p, uint32_t len, uint64_t mask) -> uint64_t {
+            const uint32_t j0 = first + (p >> 3);
+            const uint64_t hi = ((uint64_t)con(j0) << 48) | ((uint64_t)con(j0 + 1) << 32)
+                              | ((uint64_t)con(j0 + 2) << 16) | (uint64_t)con(j0 + 3);
+            const uint32_t lo = con(j0 + 4);
+            const uint32_t sh = 80u - 2u * (p & 7u) - 2u * len;
+            const uint64_t x = sh >= 16u ? (hi >> (sh - 16u)) : ((hi << (16u - sh)) | (uint64_t)(lo >> sh));
+            return x & mask;
+        };
+
+        for (uint32_t ri = 0; ri < nr; ri++) {
+            const uint32_t beg = lane_bcast(ptr_v, ri);
+            uint32_t end = lane_bcast(ptr_v, ri + 1u);
+            if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
+            uint32_t acc_t = 0xFFFFFFFFu, acc_c = 0, n_acc = 0;
+
+            uint32_t pp = beg;
+            while (pp < end) {
+                const uint32_t plen = con(pp);
+                const uint32_t first = pp + 1;
+                pp = first + (plen ? (plen - 1u) / 8u + 1u : 0u);
+                if (plen < k) continue;
+                const uint32_t nk = plen - k + 1u;
+                const uint32_t nm = plen - m + 1u;           // m-mer start positions
+
+                for (uint32_t base = 0; base < nk; base += 64u * MZ_NS) {
+                    // (1) the k-mer of every lane and the keys of the m-mers starting at
+                    //     base .. base + 64*NS - 1 + W - 1 (m-mer p = the first m bases of k-mer p)
+                    bool     active[MZ_NS], leader[MZ_NS];
+                    uint64_t c[MZ_NS];
+                    uint32_t line[MZ_NS], run[MZ_NS];
+#pragma unroll
+                    for (int s = 0; s < MZ_NS; s++) {
+                        const uint32_t p = base + 64u * s + lane;
+                        active[s] = p < nk;
+                        c[s] = 0;
+                        uint32_t key = ~0u;
+                        if (active[s]) {
+                            const uint64_t x = bases_at(first, p, k, kmask);
+                            key = mmer_key(x >> (2u * (k - m)), m);
+                            const uint64_t rc = revcomp(x, k);
+                            c[s] = x < rc ? x : rc;
+                            if (A.sharded) {
+                                const uint64_t q = div_u64(c[s], a.div);
+                                const uint64_t r = c[s] - q * a.div.d;
+                                active[s] = (r >= a.shard_begin) && (r < a.shard_end);
+                            }
+                        } else if (p < nm) {
+                            key = mmer_key(bases_at(first, p, m, mmask), m);
+                        }
+                        keyv[64 * s + lane] = key;
+                    }
+                    if (lane < W - 1u) {
+                        const uint32_t p2 = base + 64u * MZ_NS + lane;
+                        keyv[64 * MZ_NS + lane] = p2 < nm ? mmer_key(bases_at(first, p2, m, mmask), m) : ~0u;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // (2) minimizer key = window minimum, (3) line, (4) runs of equal lines
+                    uint32_t n_runs = 0, prev_last = 0xFFFFFFFFu;
+                    const uint64_t le_mask = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+#pragma unroll
+                    for (int s = 0; s < MZ_NS; s++) {
+                        uint32_t K = ~0u;
+#pragma unroll
+                        for (int i = 0; i < MZ_MAXW; i++) {
+                            const uint32_t v = keyv[64 * s + lane + i];
+                            const uint32_t vv = (uint32_t)i < W ? v : ~0u;
+                            K = vv < K ? vv : K;
+                        }
+                        line[s] = active[s] ? line_of(K, A.n_lines) : 0xFFFFFFFFu;
+                        uint32_t prev = (uint32_t)__shfl_up((int)line[s], 1, 64);
+                        if (lane == 0) prev = prev_last;                  // last lane of the previous slot
+                        prev_last = (uint32_t)__builtin_amdgcn_readlane((int)line[s], 63);
+                        leader[s] = active[s] && line[s] != prev;
+                        const uint64_t lead_mask = __ballot(leader[s]);
+                        // a run continuing from the previous slot keeps that slot's last run index
+                        run[s] = n_runs + (uint32_t)__popcll(lead_mask & le_mask) - 1u;
+                        n_runs += (uint32_t)__popcll(lead_mask);
+                    }
+
+                    bool     hit[MZ_NS];
+                    uint32_t lab[MZ_NS];
+#pragma unroll
+                    for (int s = 0; s < MZ_NS; s++) { hit[s] = false; lab[s] = 0; }
+                    for (uint32_t rb = 0; rb < n_runs; rb += MZ_RUNS) {
+#pragma unroll
+                        for (int s = 0; s < MZ_NS; s++)
+                            if (leader[s] && run[s] >= rb && run[s] < rb + MZ_RUNS) runline[run[s] - rb] = line[s];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t nb = n_runs - rb < (uint32_t)MZ_RUNS ? n_runs - rb : (uint32_t)MZ_RUNS;
+                        // 8 lanes fetch one 128-byte line; MZ_RUNS/8 rounds, all issued before use
+                        u32x4 v[MZ_RUNS / 8];
+#pragma unroll
+                        for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
+                            const uint32_t j = 8u * rd + (lane >> 3);
+                            v[rd] = u32x4{~0u, ~0u, ~0u, ~0u};
+                            if (j < nb) {
+                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)runline[j] * MZ_LINE) + (lane & 7u);
+                                v[rd] = __builtin_nontemporal_load(src);
+                            }
+                        }
+#pragma unroll
+                        for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
+                            const uint32_t j = 8u * rd + (lane >> 3);
+                            if (j < nb) *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LINE + (lane & 7u) * 16u) = v[rd];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int s = 0; s < MZ_NS; s++) {
+                            if (active[s] && run[s] >= rb && run[s] < rb + MZ_RUNS) {
+                                const uint8_t *L = linebuf + (run[s] - rb) * MZ_LINE;
+                                hit[s] = mz_match_line(L, c[s], lab[s]);
+                                const uint32_t hdr = reinterpret_cast<const uint32_t *>(L)[30];
+                                const uint32_t extra = hdr >> 8;
+                                if (!hit[s] && extra) {                       // rare: lines beyond the first
+                                    const uint32_t eb = reinterpret_cast<const uint32_t *>(L)[31];
+                                    for (uint32_t e = 0; e < extra && !hit[s]; e++) {
+                                        const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
+                                        u32x4 xv[MZ_CAP / 2];
+#pragma unroll
+                                        for (int t = 0; t < MZ_CAP / 2; t++) xv[t] = reinterpret_cast<const u32x4 *>(X)[t];
+                                        int at = -1;
+#pragma unroll
+                                        for (int t = 0; t < MZ_CAP; t++) {
+                                            const uint64_t key = (uint64_t)xv[t >> 1][2 * (t & 1)] | ((uint64_t)xv[t >> 1][2 * (t & 1) + 1] << 32);
+                                            if (key == c[s]) at = t;
+                                        }
+                                        if (at >= 0) { hit[s] = true; lab[s] = reinterpret_cast<const uint16_t *>(X + 8 * MZ_CAP)[at]; }
+                                    }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+
+                    // fold the hits into the accumulator (as in query_kernel)
+                    uint64_t mm[MZ_NS];
+                    uint64_t many = 0;
+#pragma unroll
+                    for (int s = 0; s < MZ_NS; s++) { mm[s] = __ballot(hit[s]); many |= mm[s]; }
+                    while (many) {
+                        uint32_t t = 0;
+                        bool got = false;
+#pragma unroll
+                        for (int s = 0; s < MZ_NS; s++) {
+                            if (!got && mm[s]) {
+                                t = lane_bcast(lab[s], (uint32_t)(__ffsll((unsigned long long)mm[s]) - 1));
+                                got = true;
+                            }
+                        }
+                        uint32_t cnt = 0;
+                        many = 0;
+#pragma unroll
+                        for (int s = 0; s < MZ_NS; s++) {
+                            const uint64_t same = __ballot(hit[s] && lab[s] == t);
+                            cnt += (uint32_t)__popcll(same);
+                            mm[s] &= ~same;
+                            many |= mm[s];
+                            if (lab[s] == t) hit[s] = false;
+                        }
+                        const uint64_t ex = __ballot(acc_t == t);
+                        if (ex) {
+                            if (acc_t == t) acc_c += cnt;
+                        } else if (n_acc < 64u) {
+                            if (lane == n_acc) { acc_t = t; acc_c = cnt; }
+                            n_acc++;
+                        } else {
+                            const uint32_t mx = wave_max_u32(acc_t);
+                            if (t < mx) {
+                                const uint64_t who = __ballot(acc_t == mx);
+                                if (lane == (uint32_t)(__ffsll((unsigned long long)who) - 1)) { acc_t = t; acc_c = cnt; }
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- finalisation (identical to query_kernel) ---------------------
+            const uint64_t rd = r0 + ri;
+            bool valid = lane < n_acc;
+            uint32_t rank = 0;
+            const bool need_rank = (a.flags & 2u) || (n_acc > a.maxhits);
+            if (need_rank) {
+                for (uint32_t j = 0; j < n_acc; j++) {
+                    const uint32_t tj = lane_bcast(acc_t, j);
+                    rank += (tj < acc_t) ? 1u : 0u;
+                }
+                if (n_acc > a.maxhits) {
+                    valid = valid && rank < a.maxhits;
+                    if (lane == 0) atomicAdd(a.over_maxhits, 1ull);
+                }
+            }
+            const uint32_t n_keep = n_acc > a.maxhits ? a.maxhits : n_acc;
+            if (a.flags & 2u) {
+                uint16_t *row = a.sparse_rows + rd * row_len;
+                if (lane == 0) row[0] = (uint16_t)n_keep;
+                if (valid) { row[1 + 2 * rank] = (uint16_t)acc_t; row[2 + 2 * rank] = (uint16_t)acc_c; }
+                for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
+            }
+            if (a.flags & 1u) {
+                const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
+                const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
+                const uint32_t k1  = wave_max_u32(key);
+                const uint32_t k2  = wave_max_u32(key == k1 ? 0u : key);
+                const uint32_t sum = wave_sum_u32(valid ? acc_c : 0u);
+                uint32_t out = 0;
+                switch (lane) {
+                case 0: out = sum & 0xFFFFu; break;
+                case 1: out = k1 ? (0xFFFFu - (k1 & 0xFFFFu)) + 1u : 0u; break;
+                case 2: out = k1 >> 16; break;
+                case 3: out = k2 ? (0xFFFFu - (k2 & 0xFFFFu)) + 1u : 0u; break;
+                case 4: out = k2 >> 16; break;
+                default: break;
+                }
+                if (lane < 5u) a.final_rows[rd * 5u + lane] = (uint16_t)out;
+            }
+        }
+        };   // run_group
+        if (staged) run_group(std::true_type{}); else run_group(std::false_type{});
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+} // namespace mz
+} // namespace mc

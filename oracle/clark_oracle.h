@@ -10,11 +10,15 @@
  *     lookup / .sz .ky .lb format: PINNED against the reference's own CPU hash table
  *     (src/hashTable_hh.hh, src/HashTableStorage_hh.hh) compiled from /root/reference
  *     into oracle/_ref (oracle/Makefile), fixtures in tests/golden/.
- *   - read packing, per-read scoring, sparse rows, merge, top-2: restated from
- *     src/CuCLARK_hh.hh and src/CuClarkDB.cu; the reference ships no tests, fixtures
- *     or golden vectors for them and CuClarkDB.cu needs nvcc + an NVIDIA GPU, so for
- *     these stages parity is pinned by source reading only ("parity unpinned" by a
- *     reference run).
+ *   - FASTA/FASTQ indexing, read packing, mate pairing, database build from targets and
+ *     CSV formatting: PINNED against the reference's own host driver (src/main.cc +
+ *     src/CuCLARK_hh.hh compiled into oracle/_ref/ref_host_mc_* over our backend,
+ *     tests/test_ref_host.py: byte-identical database files and CSV).
+ *   - per-read k-mer enumeration and scoring, sparse rows, merge, top-2 (the three
+ *     kernels of src/CuClarkDB.cu): restated from source; the reference ships no tests,
+ *     fixtures or golden vectors for them and CuClarkDB.cu needs nvcc + an NVIDIA GPU,
+ *     so for these stages parity is pinned by source reading only ("parity unpinned" by
+ *     a reference run).
  *
  * All "ref:" citations are relative to /root/reference/src/.
  */
