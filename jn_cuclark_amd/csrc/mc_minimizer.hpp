@@ -11,7 +11,7 @@
 // hits iff its canonical value is a stored k-mer, with that k-mer's label.  Only the
 // in-HBM arrangement differs, built once at load from the same arrays:
 //
-//   K(c)    = min over the k-m+1 windows w of canonical k-mer c of hash32(min(w, rc(w)))
+//   K(c)    = min over the k-m+1 windows w of canonical k-mer c of key64(min(w, rc(w)))
 //             (orientation-free: x and rc(x) have the same set of canonical m-mers)
 //   line(c) = mulhi(mix32(K(c)), n_lines)
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
@@ -46,31 +46,34 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 // minimizer length for a k-mer length (w = k - m + 1 windows, at most MZ_MAXW)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
 
-// 32-bit ordering hash of a canonical m-mer.  The minimizer KEY of a k-mer is the smallest
-// such hash over its windows; lines are addressed by that value, so two m-mers with equal
-// hashes merely share a line -- no tie-break is needed and x / rc(x) agree by construction.
-__device__ __forceinline__ uint32_t mmer_key(uint64_t w, uint32_t m)
+// 64-bit ordering key of a canonical m-mer (one multiply + fold: bijective, so distinct
+// m-mers never tie).  The minimizer KEY of a k-mer is the smallest such key over its
+// windows -- the same for x and rc(x), which have the same canonical m-mers.  (A 32-bit key
+// is too small: the minima of 6.4e9 k-mers crowd into a few 1e8 values and pile
+// unrelated minimizers onto the same lines.)
+__device__ __forceinline__ uint64_t mmer_key(uint64_t w, uint32_t m)
 {
     const uint64_t rc = revcomp(w, m);
-    const uint64_t z = (w < rc ? w : rc) * 0x9E3779B97F4A7C15ull;
-    return (uint32_t)(z >> 32) ^ (uint32_t)z;
+    uint64_t z = (w < rc ? w : rc) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 32;
+    return z;
 }
 
 // K(c) for a stored canonical k-mer (index build)
-__device__ __forceinline__ uint32_t kmer_min_key(uint64_t c, uint32_t k, uint32_t m)
+__device__ __forceinline__ uint64_t kmer_min_key(uint64_t c, uint32_t k, uint32_t m)
 {
     const uint64_t mmask = (1ull << (2 * m)) - 1ull;
-    uint32_t best = ~0u;
+    uint64_t best = ~0ull;
     for (uint32_t i = 0; i + m <= k; i++) {
-        const uint32_t key = mmer_key((c >> (2 * (k - m - i))) & mmask, m);
+        const uint64_t key = mmer_key((c >> (2 * (k - m - i))) & mmask, m);
         best = key < best ? key : best;
     }
     return best;
 }
 
-__device__ __forceinline__ uint32_t line_of(uint32_t K, uint32_t n_lines)
+__device__ __forceinline__ uint32_t line_of(uint64_t K, uint32_t n_lines)
 {
-    uint32_t h = K * 0x85EBCA6Bu;
+    uint32_t h = ((uint32_t)(K >> 32) * 0x85EBCA6Bu) ^ (uint32_t)K;
     h ^= h >> 15; h *= 0xC2B2AE35u; h ^= h >> 16;
     return __umulhi(h, n_lines);
 }
@@ -198,14 +201,14 @@ void mz_query_kernel(const MzArgs A)
 {
     const QueryArgs &a = A.q;
     __shared__ __attribute__((aligned(16))) uint16_t s_con[WAVES_PER_BLOCK][STAGE_CON + 16];
-    __shared__ uint32_t s_key[WAVES_PER_BLOCK][64 * MZ_NS + MZ_MAXW + 3];
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[WAVES_PER_BLOCK][64 * MZ_NS + MZ_MAXW + 3];
     __shared__ uint32_t s_runline[WAVES_PER_BLOCK][MZ_RUNS];
     __shared__ __attribute__((aligned(16))) uint8_t s_line[WAVES_PER_BLOCK][MZ_RUNS * MZ_LINE];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     uint16_t *slice = s_con[wave];
-    uint32_t *keyv = s_key[wave];
+    uint64_t *keyv = s_key[wave];
     uint32_t *runline = s_runline[wave];
     uint8_t *linebuf = s_line[wave];
 
@@ -288,7 +291,7 @@ void mz_query_kernel(const MzArgs A)
                         const uint32_t p = base + 64u * s + lane;
                         active[s] = p < nk;
                         c[s] = 0;
-                        uint32_t key = ~0u;
+                        uint64_t key = ~0ull;
                         if (active[s]) {
                             const uint64_t x = bases_at(first, p, k, kmask);
                             key = mmer_key(x >> (2u * (k - m)), m);
@@ -306,7 +309,7 @@ void mz_query_kernel(const MzArgs A)
                     }
                     if (lane < W - 1u) {
                         const uint32_t p2 = base + 64u * MZ_NS + lane;
-                        keyv[64 * MZ_NS + lane] = p2 < nm ? mmer_key(bases_at(first, p2, m, mmask), m) : ~0u;
+                        keyv[64 * MZ_NS + lane] = p2 < nm ? mmer_key(bases_at(first, p2, m, mmask), m) : ~0ull;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -315,11 +318,11 @@ void mz_query_kernel(const MzArgs A)
                     const uint64_t le_mask = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
 #pragma unroll
                     for (int s = 0; s < MZ_NS; s++) {
-                        uint32_t K = ~0u;
+                        uint64_t K = ~0ull;
 #pragma unroll
                         for (int i = 0; i < MZ_MAXW; i++) {
-                            const uint32_t v = keyv[64 * s + lane + i];
-                            const uint32_t vv = (uint32_t)i < W ? v : ~0u;
+                            const uint64_t v = keyv[64 * s + lane + i];
+                            const uint64_t vv = (uint32_t)i < W ? v : ~0ull;
                             K = vv < K ? vv : K;
                         }
                         line[s] = active[s] ? line_of(K, A.n_lines) : 0xFFFFFFFFu;
