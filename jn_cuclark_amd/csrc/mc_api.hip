@@ -74,8 +74,10 @@ struct mc_ctx {
     mc_db_info info{};
     int grid_blocks = 0;
 
-    // optional locality-aware index (mc_minimizer.hpp), selected with MC_INDEX=minimizer
-    int index_mode = 0;                // 0 = bucket lines, 1 = minimizer lines
+    // locality-aware index (mc_minimizer.hpp): the default for k >= 16; MC_INDEX=lines
+    // selects the direct bucket-line table instead (also the fallback when the minimizer
+    // lines do not fit in HBM)
+    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
     uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
     uint32_t mz_n_lines = 0, mz_m = 0;
 
@@ -217,20 +219,28 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     c->mz_n_lines = n_lines;
     c->mz_m = mc::mz::mmer_len(c->k);
     uint32_t *d_count = nullptr, *d_cursor = nullptr, *d_extra = nullptr, *d_ebase = nullptr;
-    HIPCHK(hipMalloc(&d_count, (size_t)n_lines * 4));
-    HIPCHK(hipMalloc(&d_cursor, (size_t)n_lines * 4));
-    HIPCHK(hipMalloc(&d_extra, (size_t)n_lines * 4));
-    HIPCHK(hipMalloc(&d_ebase, (size_t)n_lines * 4));
+    const size_t lbytes = (size_t)n_lines * mc::mz::MZ_LINE;
+    auto drop = [&]() {
+        if (d_count) (void)hipFree(d_count);
+        if (d_cursor) (void)hipFree(d_cursor);
+        if (d_extra) (void)hipFree(d_extra);
+        if (d_ebase) (void)hipFree(d_ebase);
+        (void)hipFree(d_koff);
+    };
+    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess || hipMalloc(&d_count, (size_t)n_lines * 4) != hipSuccess ||
+        hipMalloc(&d_cursor, (size_t)n_lines * 4) != hipSuccess || hipMalloc(&d_extra, (size_t)n_lines * 4) != hipSuccess ||
+        hipMalloc(&d_ebase, (size_t)n_lines * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        drop();
+        return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
+    }
     HIPCHK(hipMemsetAsync(d_count, 0, (size_t)n_lines * 4, st));
     HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)n_lines * 4, st));
-    const size_t lbytes = (size_t)n_lines * mc::mz::MZ_LINE;
-    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess)
-        return fail(MC_ENOMEM, "hipMalloc of " + std::to_string(lbytes) + " bytes of minimizer lines failed");
     HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, st));
     uint64_t n_extra = 0;
     int rc = c->wide ? mz_build_passes<true>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra)
                      : mz_build_passes<false>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra);
-    (void)hipFree(d_count); (void)hipFree(d_cursor); (void)hipFree(d_extra); (void)hipFree(d_ebase); (void)hipFree(d_koff);
+    drop();
     if (rc) return rc;
     c->info.htsize = c->htsize;
     c->info.shard_begin = shard_begin; c->info.shard_end = shard_end;
@@ -255,7 +265,11 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
 int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
              uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
 {
-    if (c->index_mode == 1 && c->k >= 16) return relayout_mz(c, d_sz, d_keys, d_labels, n_keys, shard_begin, shard_end);
+    if (c->index_mode == 1 && c->k >= 16) {
+        const int rcm = relayout_mz(c, d_sz, d_keys, d_labels, n_keys, shard_begin, shard_end);
+        if (rcm != MC_ENOMEM) return rcm;
+        free_db(c);                      // not enough HBM for the minimizer lines: direct table
+    }
     const uint64_t nb = shard_end - shard_begin;
     hipStream_t st = c->streams[0];
 
@@ -475,7 +489,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
     c->div = mc::make_div(htsize);
     c->wide = wide;
-    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "minimizer") == 0 ? 1 : 0;
+    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : 1;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);

@@ -34,6 +34,8 @@ static constexpr int MZ_MAXW = 13;            // windows per k-mer: w = k - m + 
 #endif
 static constexpr int MZ_NS = MC_MZ_NS;        // 64-k-mer slots per step (a 150 bp read = one step of 2)
 static constexpr int MZ_RUNS = 16 * MZ_NS;    // runs (distinct lines) fetched per batch
+static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: keeps equal offsets of different
+                                                // runs on different banks (a 128-byte stride is a 9-way conflict)
 
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -57,6 +59,19 @@ __device__ __forceinline__ uint64_t mmer_key(uint64_t w, uint32_t m)
     uint64_t z = (w < rc ? w : rc) * 0x9E3779B97F4A7C15ull;
     z ^= z >> 32;
     return z;
+}
+
+// the same from the m-mer and its reverse complement when both are at hand
+__device__ __forceinline__ uint64_t mmer_key2(uint64_t w, uint64_t rcw)
+{
+    uint64_t z = (w < rcw ? w : rcw) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 32;
+    return z;
+}
+
+__device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, uint32_t uniform_lane)
+{
+    return (uint64_t)lane_bcast((uint32_t)v, uniform_lane) | ((uint64_t)lane_bcast((uint32_t)(v >> 32), uniform_lane) << 32);
 }
 
 // K(c) for a stored canonical k-mer (index build)
@@ -194,7 +209,7 @@ __device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, u
 }
 
 #ifndef MC_MZ_MIN_WAVES
-#define MC_MZ_MIN_WAVES 1
+#define MC_MZ_MIN_WAVES 5      // measured: 4 waves/SIMD 616, 5 waves (24 B of scratch) 695 Mreads/s
 #endif
 __global__ __launch_bounds__(BLOCK_THREADS, MC_MZ_MIN_WAVES)
 void mz_query_kernel(const MzArgs A)
@@ -203,7 +218,7 @@ void mz_query_kernel(const MzArgs A)
     __shared__ __attribute__((aligned(16))) uint16_t s_con[WAVES_PER_BLOCK][STAGE_CON + 16];
     __shared__ __attribute__((aligned(16))) uint64_t s_key[WAVES_PER_BLOCK][64 * MZ_NS + MZ_MAXW + 3];
     __shared__ uint32_t s_runline[WAVES_PER_BLOCK][MZ_RUNS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_line[WAVES_PER_BLOCK][MZ_RUNS * MZ_LINE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_line[WAVES_PER_BLOCK][MZ_RUNS * MZ_LSTRIDE];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -286,30 +301,45 @@ void mz_query_kernel(const MzArgs A)
                     bool     active[MZ_NS], leader[MZ_NS];
                     uint64_t c[MZ_NS];
                     uint32_t line[MZ_NS], run[MZ_NS];
+                    // the m-mers that start behind the part's last k-mer (positions nk .. nm-1) all
+                    // lie inside that k-mer: they are cut from its value, not re-read from LDS
+                    const bool last_step = base + 64u * MZ_NS >= nk;                // wave-uniform
+                    const uint32_t last_slot = (nk - 1u - base) >> 6, last_lane = (nk - 1u - base) & 63u;
+                    uint64_t x_last = 0, rc_last = 0;
+                    auto tail_key = [&](uint32_t p) -> uint64_t {                   // nk <= p < nm
+                        const uint32_t i = p - (nk - 1u);
+                        return mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
+                    };
 #pragma unroll
                     for (int s = 0; s < MZ_NS; s++) {
                         const uint32_t p = base + 64u * s + lane;
                         active[s] = p < nk;
                         c[s] = 0;
                         uint64_t key = ~0ull;
+                        uint64_t x = 0, rc = 0;
                         if (active[s]) {
-                            const uint64_t x = bases_at(first, p, k, kmask);
-                            key = mmer_key(x >> (2u * (k - m)), m);
-                            const uint64_t rc = revcomp(x, k);
+                            x = bases_at(first, p, k, kmask);
+                            rc = revcomp(x, k);
+                            key = mmer_key2(x >> (2u * (k - m)), rc & mmask);      // first m bases, both strands
                             c[s] = x < rc ? x : rc;
                             if (A.sharded) {
                                 const uint64_t q = div_u64(c[s], a.div);
                                 const uint64_t r = c[s] - q * a.div.d;
                                 active[s] = (r >= a.shard_begin) && (r < a.shard_end);
                             }
-                        } else if (p < nm) {
-                            key = mmer_key(bases_at(first, p, m, mmask), m);
                         }
+                        if (last_step && (uint32_t)s == last_slot) {
+                            x_last = lane_bcast64(x, last_lane);
+                            rc_last = lane_bcast64(rc, last_lane);
+                        }
+                        if (p >= nk && p < nm) key = tail_key(p);
                         keyv[64 * s + lane] = key;
                     }
                     if (lane < W - 1u) {
                         const uint32_t p2 = base + 64u * MZ_NS + lane;
-                        keyv[64 * MZ_NS + lane] = p2 < nm ? mmer_key(bases_at(first, p2, m, mmask), m) : ~0ull;
+                        uint64_t key = ~0ull;
+                        if (p2 < nm) key = last_step ? tail_key(p2) : mmer_key(bases_at(first, p2, m, mmask), m);
+                        keyv[64 * MZ_NS + lane] = key;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -361,14 +391,14 @@ void mz_query_kernel(const MzArgs A)
 #pragma unroll
                         for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
                             const uint32_t j = 8u * rd + (lane >> 3);
-                            if (j < nb) *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LINE + (lane & 7u) * 16u) = v[rd];
+                            if (j < nb) *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lane & 7u) * 16u) = v[rd];
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int s = 0; s < MZ_NS; s++) {
                             if (active[s] && run[s] >= rb && run[s] < rb + MZ_RUNS) {
-                                const uint8_t *L = linebuf + (run[s] - rb) * MZ_LINE;
+                                const uint8_t *L = linebuf + (run[s] - rb) * MZ_LSTRIDE;
                                 hit[s] = mz_match_line(L, c[s], lab[s]);
                                 const uint32_t hdr = reinterpret_cast<const uint32_t *>(L)[30];
                                 const uint32_t extra = hdr >> 8;

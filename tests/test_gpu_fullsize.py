@@ -54,7 +54,7 @@ def test_full_size_table_properties(world):
     dev, genomes, raw, reads = world
     rp, con, truth, n = reads
     fin_t, info = _classify(dev, raw, reads)
-    assert info["line_bytes"] == 64 and info["n_keys"] > 6_000_000_000
+    assert info["line_bytes"] in (64, 128) and info["n_keys"] > 6_000_000_000
     assert info["device_bytes"] > 100e9
     fin = fin_t.cpu().numpy().view(np.uint16)
     npl = truth.numel()

@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 K, HT = 21, 1000003
 
 
+@pytest.fixture(params=["minimizer", "lines"], autouse=True)
+def index_mode(request, monkeypatch):
+    """every test runs on both in-HBM indexes: the minimizer index (default) and the direct
+    bucket-line table (MC_INDEX=lines)"""
+    monkeypatch.setenv("MC_INDEX", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def gpu():
     import torch
@@ -29,7 +37,7 @@ def _open(gpu, sz, ky, lb, k=K, ht=HT, maxhits=15, ntargets=16, shard=(0, 0)):
 
 
 @pytest.mark.parametrize("fmt", ["fasta", "fastq"])
-def test_mixed_reads_bit_exact(gpu, oracle, fmt):
+def test_mixed_reads_bit_exact(gpu, oracle, fmt, index_mode):
     """ragged input: N-split reads, short reads, short parts, lower case, U, all-N"""
     genomes, sz, ky, lb = small_db()
     names, seqs = mixed_fasta(genomes, K, n=2000)
@@ -43,7 +51,7 @@ def test_mixed_reads_bit_exact(gpu, oracle, fmt):
         info = db.db_info()
     assert np.array_equal(got, want)
     assert np.array_equal(rows, want_rows)
-    assert info["n_keys"] == ky.size and info["line_bytes"] == 64
+    assert info["n_keys"] == ky.size and info["line_bytes"] == (64 if index_mode == "lines" else 128)
     assert (want[:, 2] > 0).sum() > 1000
 
 
@@ -121,7 +129,7 @@ def test_many_targets_per_read_above_64(gpu, oracle):
 
 
 @pytest.mark.parametrize("line", [64, 128])
-def test_dense_buckets_overflow_table(gpu, oracle, line, monkeypatch):
+def test_dense_buckets_overflow_table(gpu, oracle, line, monkeypatch, index_mode):
     """heavily loaded table: buckets beyond a line's capacity go to the side table"""
     ht = 4099
     sz, ky, lb = synth.random_db(seed=2, htsize=ht, n_keys=60000, n_targets=40, k=K)   # ~14.6 / bucket
@@ -139,7 +147,7 @@ def test_dense_buckets_overflow_table(gpu, oracle, line, monkeypatch):
     with _open(gpu, sz, ky, lb, ht=ht, ntargets=40) as db:
         info = db.db_info()
         got = db.classify(rp, con)
-    assert info["line_bytes"] == line and info["n_overflow_buckets"] > 0
+    assert (info["line_bytes"] == line or index_mode == "minimizer") and info["n_overflow_buckets"] > 0
     assert np.array_equal(got, want)
     assert (want[:, 2] > 0).mean() > 0.45
 
@@ -288,7 +296,7 @@ def test_two_byte_keys_and_sharded_file_load(gpu, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("line", [64, 128])
-def test_wide_keys_k_and_table_size_beyond_32_bit_quotients(gpu, oracle, line, monkeypatch):
+def test_wide_keys_k_and_table_size_beyond_32_bit_quotients(gpu, oracle, line, monkeypatch, index_mode):
     """the reference's T64 regime (k = 32 with the full table, main.cc:277-286): quotients
     need 64 bits; here reached with k = 25 on a 100003-bucket table (4^25 / 100003 > 2^32)"""
     k, ht = 25, 100003
@@ -303,8 +311,9 @@ def test_wide_keys_k_and_table_size_beyond_32_bit_quotients(gpu, oracle, line, m
     with _open(gpu, sz, ky, lb, k=k, ht=ht, ntargets=6) as db:
         info = db.db_info()
         got, rows = db.classify(rp, con, extended=True)
-    assert info["line_bytes"] == line and info["line_capacity"] == (6 if line == 64 else 12)
-    assert info["n_overflow_buckets"] > 0 or line == 128
+    if index_mode == "lines":
+        assert info["line_bytes"] == line and info["line_capacity"] == (6 if line == 64 else 12)
+        assert info["n_overflow_buckets"] > 0 or line == 128
     assert np.array_equal(rows, want_rows)
     assert np.array_equal(got, oracle.result_rows(want_rows))
     assert (got[:, 2] > 0).sum() > 800
