@@ -174,12 +174,14 @@ def main():
         hr = 0.0 if hit_rate != hit_rate else hit_rate
         bytes_per_read = 54.0 + kmers_per_read * (8.0 + 4.0 * nonempty + 2.0 * hr)
         achieved = bytes_per_read * n_reads / (kern_ms_avg * 1e-3) / 1e9
+        index = "lines" if os.environ.get("MC_INDEX") == "lines" or info["line_bytes"] == 64 else "minimizer"
+        kernel_name = "mc::mz::mz_query_kernel" if index == "minimizer" else "mc::query_kernel<%d, false>" % info["line_bytes"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("reads_per_launch") == n_reads and tj.get("line_bytes") == info["line_bytes"]:
+                if tj.get("reads_per_launch") == n_reads and tj.get("kernel") == kernel_name and tj.get("htsize") == ht:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -191,9 +193,9 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {
                 "workload": "cuCLARK full table HTSIZE=%d k=%d, %.2fe9 k-mers of %d targets in HBM "
-                            "(%d-byte bucket lines), %d x %dbp reads per step per GPU, inputs resident in HBM"
+                            "(%s index, %d-byte lines), %d x %dbp reads per step per GPU, inputs resident in HBM"
                             % (ht, k, n_keys * (world if shard_mode else 1) / 1e9, args.targets,
-                               info["line_bytes"], n_reads, READ_LEN),
+                               index, info["line_bytes"], n_reads, READ_LEN),
                 "reads_per_step": n_reads * (1 if shard_mode else world), "k": k, "htsize": ht,
                 "n_kmers_db": n_keys, "targets": args.targets, "maxhits": MAXHITS,
                 "parallelism": ("shard%d+all_to_all" % world) if shard_mode else ("replica%d" % world),
@@ -201,12 +203,12 @@ def main():
                 "reads_assigned": round(assigned, 4), "reads_over_maxhits": st["reads_over_maxhits"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "mc::query_kernel<%d, false>" % info["line_bytes"],
+                "bound": "hbm", "kernel": kernel_name, "index": index,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel_ms": round(kern_ms_avg, 4), "algorithmic_bytes_per_read": round(bytes_per_read, 1),
-                "probes_per_s": round(kmers_per_read * n_reads / (kern_ms_avg * 1e-3), 1),
-                "line_gather_GBs": round(kmers_per_read * n_reads * info["line_bytes"] / (kern_ms_avg * 1e-3) / 1e9, 2),
+                "kmers_per_s": round(kmers_per_read * n_reads / (kern_ms_avg * 1e-3), 1),
+                "hbm_traffic_GBs": None if traffic is None else round(traffic / (kern_ms_avg * 1e-3) / 1e9, 1),
             },
         }
 

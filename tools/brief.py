@@ -8,5 +8,5 @@ for line in sys.stdin:
         continue
     d = json.loads(line)
     r = d["roofline"]
-    print(tag, "Mreads/s=%.1f" % d["value"], "kernel_ms=%.3f" % r["kernel_ms"], "gather_GB/s=%.0f" % r["line_gather_GBs"],
+    print(tag, "Mreads/s=%.1f" % d["value"], "kernel_ms=%.3f" % r["kernel_ms"], "index=%s" % r.get("index"),
           "alg_GB/s=%.0f" % r["achieved"], "hit=%s" % d["config"].get("kmer_hit_rate"), flush=True)
