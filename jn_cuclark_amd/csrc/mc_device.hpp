@@ -124,7 +124,10 @@ struct QueryArgs {
 static constexpr int WAVES_PER_BLOCK = 4;
 static constexpr int BLOCK_THREADS   = 64 * WAVES_PER_BLOCK;
 static constexpr int GROUP_READS     = 16;     // reads staged per wave at a time
-static constexpr int STAGE_CON       = 1024;   // u16 containers per wave LDS slice
+#ifndef MC_STAGE_CON
+#define MC_STAGE_CON 1024
+#endif
+static constexpr int STAGE_CON       = MC_STAGE_CON;   // u16 containers per wave LDS slice
 
 // reverse complement: complement every 2-bit code, reverse the order of the codes,
 // keep the low 2k bits.  Same function as reference CuClarkDB.cu:1196-1203, written
@@ -300,12 +303,18 @@ void query_kernel(const QueryArgs a)
         // container offsets of the group's reads: lane i holds reads_ptr[r0 + i]
         uint32_t ptr_v = 0;
         if (lane <= nr) ptr_v = a.reads_ptr[r0 + lane];
-        const uint32_t c0 = __builtin_amdgcn_readlane(ptr_v, 0);
-        const uint32_t c1 = lane_bcast(ptr_v, nr);
+        // The group is staged into the wave's LDS slice in as few pieces as fit: usually all
+        // 16 reads at once; long reads (2 x 250 bp pairs, contigs) in smaller pieces; a single
+        // read larger than the slice is read from global memory.
+        for (uint32_t rs = 0; rs < nr;) {
+        const uint32_t c0 = lane_bcast(ptr_v, rs);
         const uint32_t c0a = c0 & ~7u;
+        const uint64_t fits = __ballot(lane > rs && lane <= nr && (ptr_v - c0a) <= (uint32_t)STAGE_CON);
+        const bool staged = a.stage_ok && fits != 0;
+        const uint32_t re = staged ? (uint32_t)(63 - __builtin_clzll((unsigned long long)fits)) : rs + 1u;
+        const uint32_t c1 = lane_bcast(ptr_v, re);
 
         // stage [c0a, c1) into this wave's LDS slice (16-byte loads, coalesced)
-        const bool staged = a.stage_ok && (c1 - c0a) <= (uint32_t)STAGE_CON;
         if (staged) {
             for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
                 const uint64_t gi = (uint64_t)c0a + j;
@@ -338,7 +347,7 @@ void query_kernel(const QueryArgs a)
             }
         };
 
-        for (uint32_t ri = 0; ri < nr; ri++) {
+        for (uint32_t ri = rs; ri < re; ri++) {
             const uint32_t beg = lane_bcast(ptr_v, ri);
             uint32_t end = lane_bcast(ptr_v, ri + 1u);
             if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
@@ -511,6 +520,11 @@ void query_kernel(const QueryArgs a)
         }
         };   // run_group
         if (staged) run_group(std::true_type{}); else run_group(std::false_type{});
+        rs = re;
+        // the slice is rewritten by the next piece: keep the compiler from hoisting its stores
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        }   // pieces of the group
         // the slice is rewritten by the next group: keep the compiler from hoisting
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

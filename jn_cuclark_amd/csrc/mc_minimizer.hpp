@@ -33,7 +33,10 @@ static constexpr int MZ_MAXW = 13;            // windows per k-mer: w = k - m + 
 #define MC_MZ_NS 2
 #endif
 static constexpr int MZ_NS = MC_MZ_NS;        // 64-k-mer slots per step (a 150 bp read = one step of 2)
-static constexpr int MZ_RUNS = 16 * MZ_NS;    // runs (distinct lines) fetched per batch
+#ifndef MC_MZ_RUNS
+#define MC_MZ_RUNS (16 * MC_MZ_NS)
+#endif
+static constexpr int MZ_RUNS = MC_MZ_RUNS;    // runs (distinct lines) fetched per batch (multiple of 8)
 static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: keeps equal offsets of different
                                                 // runs on different banks (a 128-byte stride is a 9-way conflict)
 
@@ -240,10 +243,16 @@ void mz_query_kernel(const MzArgs A)
         const uint32_t nr = (uint32_t)((a.n_reads - r0) < GROUP_READS ? (a.n_reads - r0) : GROUP_READS);
         uint32_t ptr_v = 0;
         if (lane <= nr) ptr_v = a.reads_ptr[r0 + lane];
-        const uint32_t c0 = __builtin_amdgcn_readlane(ptr_v, 0);
-        const uint32_t c1 = lane_bcast(ptr_v, nr);
+        // The group is staged into the wave's LDS slice in as few pieces as fit: usually all
+        // 16 reads at once; long reads (2 x 250 bp pairs, contigs) in smaller pieces; a single
+        // read larger than the slice is read from global memory.
+        for (uint32_t rs = 0; rs < nr;) {
+        const uint32_t c0 = lane_bcast(ptr_v, rs);
         const uint32_t c0a = c0 & ~7u;
-        const bool staged = a.stage_ok && (c1 - c0a) <= (uint32_t)STAGE_CON;
+        const uint64_t fits = __ballot(lane > rs && lane <= nr && (ptr_v - c0a) <= (uint32_t)STAGE_CON);
+        const bool staged = a.stage_ok && fits != 0;
+        const uint32_t re = staged ? (uint32_t)(63 - __builtin_clzll((unsigned long long)fits)) : rs + 1u;
+        const uint32_t c1 = lane_bcast(ptr_v, re);
         if (staged) {
             for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
                 const uint64_t gi = (uint64_t)c0a + j;
@@ -280,7 +289,7 @@ void mz_query_kernel(const MzArgs A)
             return x & mask;
         };
 
-        for (uint32_t ri = 0; ri < nr; ri++) {
+        for (uint32_t ri = rs; ri < re; ri++) {
             const uint32_t beg = lane_bcast(ptr_v, ri);
             uint32_t end = lane_bcast(ptr_v, ri + 1u);
             if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
@@ -508,6 +517,11 @@ void mz_query_kernel(const MzArgs A)
         }
         };   // run_group
         if (staged) run_group(std::true_type{}); else run_group(std::false_type{});
+        rs = re;
+        // the slice is rewritten by the next piece: keep the compiler from hoisting its stores
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        }   // pieces of the group
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

@@ -317,3 +317,20 @@ def test_wide_keys_k_and_table_size_beyond_32_bit_quotients(gpu, oracle, line, m
     assert np.array_equal(rows, want_rows)
     assert np.array_equal(got, oracle.result_rows(want_rows))
     assert (got[:, 2] > 0).sum() > 800
+
+
+def test_paired_250bp_reads_are_staged_in_pieces(gpu, oracle):
+    """BASELINE config 5 shape: 2 x 250 bp pairs joined by N (501 bases, 66 containers per
+    read): 16 of them exceed a wave's LDS slice, so the group is staged in pieces"""
+    genomes, sz, ky, lb = small_db(glen=8000, n_targets=5)
+    c1, _ = synth.sample_reads(genomes, 700, 250, seed=21)
+    c2, _ = synth.sample_reads(genomes, 700, 250, seed=22)
+    seqs = [synth.codes_to_ascii(a) + b"N" + synth.codes_to_ascii(b) for a, b in zip(c1, c2)]
+    seqs[5] = synth.codes_to_ascii(genomes[0][:7000])           # one contig-like read in the middle
+    text = synth.fasta_text([b"p%d" % i for i in range(len(seqs))], seqs)
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    want, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).classify(K, rp, con, 15)
+    with _open(gpu, sz, ky, lb) as db:
+        got = db.classify(rp, con)
+    assert np.array_equal(got, want)
+    assert (want[:, 0] > 300).sum() > 500
