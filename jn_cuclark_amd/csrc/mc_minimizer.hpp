@@ -256,12 +256,17 @@ void mz_query_kernel(const MzArgs A)
         if (staged) {
             for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
                 const uint64_t gi = (uint64_t)c0a + j;
+                // the slice holds the containers as big-endian 64-bit words (4 containers each,
+                // first base in the top bits): container i lives at u16 index i ^ 3, and any
+                // k-mer is cut from two consecutive aligned words
                 if (gi + 8u <= a.n_containers) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(a.containers + gi);
-                    *reinterpret_cast<uint4 *>(slice + j) = v;
+                    *reinterpret_cast<uint4 *>(slice + j) =
+                        make_uint4(__builtin_rotateright32(v.y, 16), __builtin_rotateright32(v.x, 16),
+                                   __builtin_rotateright32(v.w, 16), __builtin_rotateright32(v.z, 16));
                 } else {
                     for (uint32_t t = 0; t < 8u; t++)
-                        slice[j + t] = (gi + t < a.n_containers) ? a.containers[gi + t] : (uint16_t)0;
+                        slice[(j + t) ^ 3u] = (gi + t < a.n_containers) ? a.containers[gi + t] : (uint16_t)0;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -272,7 +277,7 @@ void mz_query_kernel(const MzArgs A)
         auto con = [&](uint32_t i) -> uint32_t {
             if constexpr (STAGED) {
                 const uint32_t li = i - c0a;
-                return slice[li < (uint32_t)(STAGE_CON + 15) ? li : (uint32_t)(STAGE_CON + 15)];
+                return slice[(li < (uint32_t)(STAGE_CON + 12) ? li : (uint32_t)(STAGE_CON + 12)) ^ 3u];
             } else {
                 const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
                 return a.containers[ii];
@@ -280,6 +285,15 @@ void mz_query_kernel(const MzArgs A)
         };
         // `len` bases starting at base position p of the part whose containers start at `first`
         auto bases_at = [&](uint32_t first, uint32_t p, uint32_t len, uint64_t mask) -> uint64_t {
+            if constexpr (STAGED) {
+                uint32_t j0 = first - c0a + (p >> 3);                         // container index in the slice
+                if (j0 > (uint32_t)(STAGE_CON + 4)) j0 = (uint32_t)(STAGE_CON + 4);
+                const uint64_t *w = reinterpret_cast<const uint64_t *>(slice) + (j0 >> 2);
+                const uint64_t wa = w[0], wb = w[1];
+                const uint32_t b = 16u * (j0 & 3u) + 2u * (p & 7u);           // bit offset of the first base
+                const uint64_t top = (wa << b) | (b ? (wb >> (64u - b)) : 0ull);
+                return (top >> (64u - 2u * len)) & mask;
+            }
             const uint32_t j0 = first + (p >> 3);
             const uint64_t hi = ((uint64_t)con(j0) << 48) | ((uint64_t)con(j0 + 1) << 32)
                               | ((uint64_t)con(j0 + 2) << 16) | (uint64_t)con(j0 + 3);
