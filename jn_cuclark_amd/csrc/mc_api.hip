@@ -38,6 +38,23 @@ int fail(int code, const std::string &msg)
             return fail(MC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
+// Device temporaries of one API call: released when the call returns, on every path.
+struct Scope {
+    std::vector<void *> ptrs;
+    ~Scope() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    void add(void *p) { ptrs.push_back(p); }
+    void drop(void *p)      // release early (large temporaries), or after ownership moved on
+    {
+        for (auto &q : ptrs) if (q == p && p) { (void)hipFree(p); q = nullptr; }
+    }
+    void forget(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }
+};
+#define TMP_MALLOC(scope, ptr, bytes)                                                   \
+    do {                                                                                \
+        HIPCHK(hipMalloc(&(ptr), (bytes)));                                             \
+        (scope).add(ptr);                                                               \
+    } while (0)
+
 struct Batch {
     uint32_t *h_ptr = nullptr;
     uint16_t *h_con = nullptr;
@@ -136,9 +153,10 @@ int scan_u32_device(mc_ctx *c, const uint32_t *d_v, uint64_t n, uint32_t *d_out,
 {
     hipStream_t st = c->streams[0];
     const uint32_t nblk = (uint32_t)((n + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    Scope tmp;
     unsigned long long *d_blk = nullptr; uint64_t *d_boff = nullptr;
-    HIPCHK(hipMalloc(&d_blk, (size_t)nblk * 8));
-    HIPCHK(hipMalloc(&d_boff, (size_t)nblk * 8));
+    TMP_MALLOC(tmp, d_blk, (size_t)nblk * 8);
+    TMP_MALLOC(tmp, d_boff, (size_t)nblk * 8);
     hipLaunchKernelGGL(mc::mz::mz_blocksum_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_v, n, d_blk);
     HIPCHK(hipGetLastError());
     std::vector<unsigned long long> blk(nblk);
@@ -152,7 +170,6 @@ int scan_u32_device(mc_ctx *c, const uint32_t *d_v, uint64_t n, uint32_t *d_out,
     hipLaunchKernelGGL(mc::mz::mz_scan_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_v, n, d_boff, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    (void)hipFree(d_blk); (void)hipFree(d_boff);
     *total = acc;
     return MC_OK;
 }
@@ -193,21 +210,21 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     const uint64_t nb = shard_end - shard_begin;
     hipStream_t st = c->streams[0];
     const uint32_t nblk = (uint32_t)((nb + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    Scope tmp;
     uint32_t *d_bk = nullptr, *d_bo = nullptr;
-    HIPCHK(hipMalloc(&d_bk, (size_t)nblk * 4));
-    HIPCHK(hipMalloc(&d_bo, (size_t)nblk * 4));
+    TMP_MALLOC(tmp, d_bk, (size_t)nblk * 4);
+    TMP_MALLOC(tmp, d_bo, (size_t)nblk * 4);
     hipLaunchKernelGGL(mc::block_sums_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz, nb, 255u, d_bk, d_bo);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> bk(nblk);
     HIPCHK(hipMemcpyAsync(bk.data(), d_bk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    (void)hipFree(d_bk); (void)hipFree(d_bo);
     std::vector<uint64_t> koff(nblk);
     uint64_t ak = 0;
     for (uint32_t i = 0; i < nblk; i++) { koff[i] = ak; ak += bk[i]; }
     if (ak != n_keys) return fail(MC_EINVAL, "bucket sizes do not sum to n_keys");
     uint64_t *d_koff = nullptr;
-    HIPCHK(hipMalloc(&d_koff, (size_t)nblk * 8));
+    TMP_MALLOC(tmp, d_koff, (size_t)nblk * 8);
     HIPCHK(hipMemcpyAsync(d_koff, koff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
 
     free_db(c);
@@ -220,18 +237,13 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     c->mz_m = mc::mz::mmer_len(c->k);
     uint32_t *d_count = nullptr, *d_cursor = nullptr, *d_extra = nullptr, *d_ebase = nullptr;
     const size_t lbytes = (size_t)n_lines * mc::mz::MZ_LINE;
-    auto drop = [&]() {
-        if (d_count) (void)hipFree(d_count);
-        if (d_cursor) (void)hipFree(d_cursor);
-        if (d_extra) (void)hipFree(d_extra);
-        if (d_ebase) (void)hipFree(d_ebase);
-        (void)hipFree(d_koff);
+    auto grab = [&](uint32_t *&ptr) {
+        if (hipMalloc(&ptr, (size_t)n_lines * 4) != hipSuccess) return false;
+        tmp.add(ptr);
+        return true;
     };
-    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess || hipMalloc(&d_count, (size_t)n_lines * 4) != hipSuccess ||
-        hipMalloc(&d_cursor, (size_t)n_lines * 4) != hipSuccess || hipMalloc(&d_extra, (size_t)n_lines * 4) != hipSuccess ||
-        hipMalloc(&d_ebase, (size_t)n_lines * 4) != hipSuccess) {
+    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess || !grab(d_count) || !grab(d_cursor) || !grab(d_extra) || !grab(d_ebase)) {
         (void)hipGetLastError();
-        drop();
         return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
     }
     HIPCHK(hipMemsetAsync(d_count, 0, (size_t)n_lines * 4, st));
@@ -240,7 +252,6 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     uint64_t n_extra = 0;
     int rc = c->wide ? mz_build_passes<true>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra)
                      : mz_build_passes<false>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra);
-    drop();
     if (rc) return rc;
     c->info.htsize = c->htsize;
     c->info.shard_begin = shard_begin; c->info.shard_end = shard_end;
@@ -274,8 +285,9 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t 
     hipStream_t st = c->streams[0];
 
     // 1. histogram of bucket sizes -> line size
+    Scope tmp;
     unsigned long long *d_hist = nullptr;
-    HIPCHK(hipMalloc(&d_hist, 256 * sizeof(unsigned long long)));
+    TMP_MALLOC(tmp, d_hist, 256 * sizeof(unsigned long long));
     HIPCHK(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), st));
     {
         const uint64_t want = (nb + 256 * 64 - 1) / (256 * 64);
@@ -286,7 +298,6 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t 
     unsigned long long hist[256];
     HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    (void)hipFree(d_hist);
 
     uint64_t total = 0, nonempty = 0;
     for (int i = 0; i < 256; i++) { total += hist[i] * (uint64_t)i; if (i) nonempty += hist[i]; }
@@ -308,21 +319,20 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t 
     const uint32_t nblk = (uint32_t)((nb + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
     uint32_t *d_bk = nullptr, *d_bo = nullptr;
     uint64_t *d_koff = nullptr, *d_ooff = nullptr;
-    HIPCHK(hipMalloc(&d_bk, (size_t)nblk * 4));
-    HIPCHK(hipMalloc(&d_bo, (size_t)nblk * 4));
+    TMP_MALLOC(tmp, d_bk, (size_t)nblk * 4);
+    TMP_MALLOC(tmp, d_bo, (size_t)nblk * 4);
     hipLaunchKernelGGL(mc::block_sums_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz, nb, (uint32_t)cap, d_bk, d_bo);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> bk(nblk), bo(nblk);
     HIPCHK(hipMemcpyAsync(bk.data(), d_bk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(bo.data(), d_bo, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    (void)hipFree(d_bk); (void)hipFree(d_bo);
     std::vector<uint64_t> koff(nblk), ooff(nblk);
     uint64_t ak = 0, ao = 0;
     for (uint32_t i = 0; i < nblk; i++) { koff[i] = ak; ooff[i] = ao; ak += bk[i]; ao += bo[i]; }
     if (ak != n_keys || ao != n_ovf_k) return fail(MC_EINVAL, "internal: block sums disagree with histogram");
-    HIPCHK(hipMalloc(&d_koff, (size_t)nblk * 8));
-    HIPCHK(hipMalloc(&d_ooff, (size_t)nblk * 8));
+    TMP_MALLOC(tmp, d_koff, (size_t)nblk * 8);
+    TMP_MALLOC(tmp, d_ooff, (size_t)nblk * 8);
     HIPCHK(hipMemcpyAsync(d_koff, koff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_ooff, ooff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
 
@@ -330,7 +340,7 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t 
     free_db(c);
     const size_t line_bytes = (size_t)nb * line;
     if (hipMalloc(&c->d_lines, line_bytes ? line_bytes : 16) != hipSuccess) {
-        (void)hipFree(d_koff); (void)hipFree(d_ooff);
+        (void)hipGetLastError();
         return fail(MC_ENOMEM, "hipMalloc of " + std::to_string(line_bytes) + " bytes of bucket lines failed");
     }
     HIPCHK(hipMalloc(&c->d_ovf_keys, (size_t)(n_ovf_k ? n_ovf_k : 4) * kb));
@@ -342,7 +352,6 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t 
                                   : launch_fill<128, true>(c, d_sz, d_keys, d_labels, nb, d_koff, d_ooff, nblk);
     if (rc != MC_OK) return rc;
     HIPCHK(hipStreamSynchronize(st));
-    (void)hipFree(d_koff); (void)hipFree(d_ooff);
 
     c->info.htsize = c->htsize;
     c->info.shard_begin = shard_begin;
@@ -387,6 +396,8 @@ int convert_keys(mc_ctx *c, void *d_raw, int key_bytes, uint64_t n, bool raw_own
 {
     const int want = c->wide ? 8 : 4;
     if (key_bytes == want) { *out = d_raw; *out_owned = raw_owned; return MC_OK; }
+    Scope raw;                                   // the raw array, if ours, is released on every path below
+    if (raw_owned) raw.add(d_raw);
     if (key_bytes > want)
         return fail(MC_EINVAL, "8-byte key file for a k/htsize whose quotients fit 4 bytes: rebuild the database "
                                "(the reference writes 4-byte keys here, src/main.cc:267-275)");
@@ -395,7 +406,6 @@ int convert_keys(mc_ctx *c, void *d_raw, int key_bytes, uint64_t n, bool raw_own
     int rc;
     if (key_bytes == 2) rc = c->wide ? widen<uint16_t, uint64_t>(c, d_raw, n, d) : widen<uint16_t, uint32_t>(c, d_raw, n, d);
     else                rc = widen<uint32_t, uint64_t>(c, d_raw, n, d);
-    if (raw_owned) (void)hipFree(d_raw);
     if (rc != MC_OK) { (void)hipFree(d); return rc; }
     *out = d; *out_owned = true;
     return MC_OK;
@@ -522,12 +532,12 @@ int mc_load_db_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int ke
     if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
     int rc = set_dev(c); if (rc) return rc;
     rc = norm_shard(c, sb, se); if (rc) return rc;
+    Scope tmp;
     void *keys = nullptr; bool owned = false;
     rc = convert_keys(c, const_cast<void *>(d_keys), key_bytes, n_keys, false, &keys, &owned);
     if (rc) return rc;
-    rc = relayout(c, d_sz, keys, d_labels, n_keys, sb, se);
-    if (owned) (void)hipFree(keys);
-    return rc;
+    if (owned) tmp.add(keys);
+    return relayout(c, d_sz, keys, d_labels, n_keys, sb, se);
 }
 
 int mc_load_db_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,
@@ -543,20 +553,22 @@ int mc_load_db_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_byte
     for (uint64_t b = sb; b < se; b++) kn += sz[b];
     if (k0 + kn > n_keys) return fail(MC_EINVAL, "bucket sizes exceed n_keys");
     const uint64_t nb = se - sb;
+    Scope tmp;
     uint8_t *d_sz = nullptr; void *d_raw = nullptr; uint16_t *d_labels = nullptr;
-    HIPCHK(hipMalloc(&d_sz, nb ? nb : 1));
-    HIPCHK(hipMalloc(&d_raw, (kn ? kn : 1) * (size_t)key_bytes));
-    HIPCHK(hipMalloc(&d_labels, (kn ? kn : 1) * 2));
+    TMP_MALLOC(tmp, d_sz, nb ? nb : 1);
+    TMP_MALLOC(tmp, d_raw, (kn ? kn : 1) * (size_t)key_bytes);
+    TMP_MALLOC(tmp, d_labels, (kn ? kn : 1) * 2);
     HIPCHK(hipMemcpy(d_sz, sz + sb, nb, hipMemcpyHostToDevice));
     if (kn) {
         HIPCHK(hipMemcpy(d_raw, (const char *)keys + k0 * (size_t)key_bytes, kn * (size_t)key_bytes, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_labels, labels + k0, kn * 2, hipMemcpyHostToDevice));
     }
     void *d_keys = nullptr; bool owned = false;
+    tmp.forget(d_raw);                       // convert_keys takes it over (frees or returns it)
     rc = convert_keys(c, d_raw, key_bytes, kn, true, &d_keys, &owned);
-    if (rc == MC_OK) rc = relayout(c, d_sz, d_keys, d_labels, kn, sb, se);
-    (void)hipFree(d_sz); (void)hipFree(d_keys); (void)hipFree(d_labels);
-    return rc;
+    if (rc != MC_OK) return rc;
+    tmp.add(d_keys);
+    return relayout(c, d_sz, d_keys, d_labels, kn, sb, se);
 }
 
 int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, uint64_t sb, uint64_t se)
@@ -589,10 +601,11 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
         else if (i < se && kp) kept += sz[i];
     }
     const uint64_t nb = se - sb;
+    Scope tmp;
     uint8_t *d_sz = nullptr; char *d_raw = nullptr; uint16_t *d_labels = nullptr;
-    HIPCHK(hipMalloc(&d_sz, nb ? nb : 1));
-    HIPCHK(hipMalloc(&d_raw, (kept ? kept : 1) * (size_t)key_bytes));
-    HIPCHK(hipMalloc(&d_labels, (kept ? kept : 1) * 2));
+    TMP_MALLOC(tmp, d_sz, nb ? nb : 1);
+    TMP_MALLOC(tmp, d_raw, (kept ? kept : 1) * (size_t)key_bytes);
+    TMP_MALLOC(tmp, d_labels, (kept ? kept : 1) * 2);
 
     // stream the shard's keys/labels through a staging buffer, dropping unsampled buckets
     const uint64_t CH = 1ull << 24;   // buckets per step
@@ -633,10 +646,11 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
     if (dpos != kept) return fail(MC_EINVAL, "internal: kept-key count mismatch");
     HIPCHK(hipMemcpy(d_sz, sz.data() + sb, nb, hipMemcpyHostToDevice));
     void *d_keys = nullptr; bool owned = false;
+    tmp.forget(d_raw);                       // convert_keys takes it over (frees or returns it)
     rc = convert_keys(c, d_raw, key_bytes, kept, true, &d_keys, &owned);
-    if (rc == MC_OK) rc = relayout(c, d_sz, d_keys, d_labels, kept, sb, se);
-    (void)hipFree(d_sz); (void)hipFree(d_keys); (void)hipFree(d_labels);
-    return rc;
+    if (rc != MC_OK) return rc;
+    tmp.add(d_keys);
+    return relayout(c, d_sz, d_keys, d_labels, kept, sb, se);
 }
 
 int mc_get_db_info(mc_ctx *c, mc_db_info *out)
