@@ -514,9 +514,16 @@ void mz_query_kernel(const MzArgs A)
             if (a.flags & 1u) {
                 const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
                 const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
-                const uint32_t k1  = wave_max_u32(key);
-                const uint32_t k2  = wave_max_u32(key == k1 ? 0u : key);
-                const uint32_t sum = wave_sum_u32(valid ? acc_c : 0u);
+                uint32_t k1, k2, sum;
+                if (n_acc <= 1u) {              // most reads hit no target or one: nothing to reduce
+                    k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
+                    k2 = 0u;
+                    sum = (uint32_t)__builtin_amdgcn_readlane((int)(valid ? acc_c : 0u), 0);
+                } else {
+                    k1  = wave_max_u32(key);
+                    k2  = wave_max_u32(key == k1 ? 0u : key);
+                    sum = wave_sum_u32(valid ? acc_c : 0u);
+                }
                 uint32_t out = 0;
                 switch (lane) {
                 case 0: out = sum & 0xFFFFu; break;
