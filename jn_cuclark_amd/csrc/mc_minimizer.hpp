@@ -51,17 +51,29 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
 // minimizer length for a k-mer length (w = k - m + 1 windows, at most MZ_MAXW)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
 
-// 64-bit ordering key of a canonical m-mer (one multiply + fold: bijective, so distinct
-// m-mers never tie).  The minimizer KEY of a k-mer is the smallest such key over its
-// windows -- the same for x and rc(x), which have the same canonical m-mers.  (A 32-bit key
-// is too small: the minima of 6.4e9 k-mers crowd into a few 1e8 values and pile
-// unrelated minimizers onto the same lines.)
+// Ordering key of a canonical m-mer: one 64-bit multiply-fold, of which the top 52 bits
+// are kept as the mantissa of a double in [1, 2).  For such doubles numeric order = integer
+// order of the bit pattern, so the window minimum is ONE v_min_f64 per element instead of a
+// 64-bit compare and two selects.  The minimizer KEY of a k-mer is the smallest key over its
+// windows -- the same for x and rc(x), which contain the same canonical m-mers; two m-mers
+// that share a key (2^-52) merely share lines.  (32-bit keys are too few: the minima of
+// 6.4e9 k-mers crowd into a few 1e8 values and pile unrelated minimizers onto a line.)
+static constexpr uint64_t MZ_KEY_ONE = 0x3FF0000000000000ull;     // 1.0
+static constexpr uint64_t MZ_KEY_NONE = 0x4000000000000000ull;    // 2.0: above every key
+
 __device__ __forceinline__ uint64_t mmer_key(uint64_t w, uint32_t m)
 {
     const uint64_t rc = revcomp(w, m);
     uint64_t z = (w < rc ? w : rc) * 0x9E3779B97F4A7C15ull;
     z ^= z >> 32;
-    return z;
+    return MZ_KEY_ONE | (z >> 12);
+}
+
+__device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
+    return __builtin_bit_cast(uint64_t, r);
 }
 
 // the same from the m-mer and its reverse complement when both are at hand
@@ -69,7 +81,7 @@ __device__ __forceinline__ uint64_t mmer_key2(uint64_t w, uint64_t rcw)
 {
     uint64_t z = (w < rcw ? w : rcw) * 0x9E3779B97F4A7C15ull;
     z ^= z >> 32;
-    return z;
+    return MZ_KEY_ONE | (z >> 12);
 }
 
 __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, uint32_t uniform_lane)
@@ -81,10 +93,10 @@ __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, uint32_t uniform_la
 __device__ __forceinline__ uint64_t kmer_min_key(uint64_t c, uint32_t k, uint32_t m)
 {
     const uint64_t mmask = (1ull << (2 * m)) - 1ull;
-    uint64_t best = ~0ull;
+    uint64_t best = MZ_KEY_NONE;
     for (uint32_t i = 0; i + m <= k; i++) {
         const uint64_t key = mmer_key((c >> (2 * (k - m - i))) & mmask, m);
-        best = key < best ? key : best;
+        best = key < best ? key : best;          // same order as v_min_f64 on these patterns
     }
     return best;
 }
@@ -232,6 +244,7 @@ void mz_query_kernel(const MzArgs A)
 
     const uint32_t k = a.k, m = A.m;
     const uint32_t W = k - m + 1;
+    const bool full_w = W == MZ_MAXW;          // always, with m = k - 12
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
     const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
@@ -338,7 +351,7 @@ void mz_query_kernel(const MzArgs A)
                         const uint32_t p = base + 64u * s + lane;
                         active[s] = p < nk;
                         c[s] = 0;
-                        uint64_t key = ~0ull;
+                        uint64_t key = MZ_KEY_NONE;
                         uint64_t x = 0, rc = 0;
                         if (active[s]) {
                             x = bases_at(first, p, k, kmask);
@@ -360,7 +373,7 @@ void mz_query_kernel(const MzArgs A)
                     }
                     if (lane < W - 1u) {
                         const uint32_t p2 = base + 64u * MZ_NS + lane;
-                        uint64_t key = ~0ull;
+                        uint64_t key = MZ_KEY_NONE;
                         if (p2 < nm) key = last_step ? tail_key(p2) : mmer_key(bases_at(first, p2, m, mmask), m);
                         keyv[64 * MZ_NS + lane] = key;
                     }
@@ -371,12 +384,15 @@ void mz_query_kernel(const MzArgs A)
                     const uint64_t le_mask = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
 #pragma unroll
                     for (int s = 0; s < MZ_NS; s++) {
-                        uint64_t K = ~0ull;
+                        uint64_t K = MZ_KEY_NONE, v[MZ_MAXW];
 #pragma unroll
-                        for (int i = 0; i < MZ_MAXW; i++) {
-                            const uint64_t v = keyv[64 * s + lane + i];
-                            const uint64_t vv = (uint32_t)i < W ? v : ~0ull;
-                            K = vv < K ? vv : K;
+                        for (int i = 0; i < MZ_MAXW; i++) v[i] = keyv[64 * s + lane + i];
+                        if (full_w) {
+#pragma unroll
+                            for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, v[i]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, (uint32_t)i < W ? v[i] : MZ_KEY_NONE);
                         }
                         line[s] = active[s] ? line_of(K, A.n_lines) : 0xFFFFFFFFu;
                         uint32_t prev = (uint32_t)__shfl_up((int)line[s], 1, 64);
