@@ -395,8 +395,8 @@ void mz_query_kernel(const MzArgs A)
                             for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, (uint32_t)i < W ? v[i] : MZ_KEY_NONE);
                         }
                         line[s] = active[s] ? line_of(K, A.n_lines) : 0xFFFFFFFFu;
-                        uint32_t prev = (uint32_t)__shfl_up((int)line[s], 1, 64);
-                        if (lane == 0) prev = prev_last;                  // last lane of the previous slot
+                        // line of the lane before (DPP wave_shr:1); lane 0 sees the previous slot's last lane
+                        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_last, (int)line[s], 0x138, 0xf, 0xf, false);
                         prev_last = (uint32_t)__builtin_amdgcn_readlane((int)line[s], 63);
                         leader[s] = active[s] && line[s] != prev;
                         const uint64_t lead_mask = __ballot(leader[s]);
