@@ -213,13 +213,33 @@ struct MzArgs {
     uint32_t sharded;          // apply the bucket-range filter (r = c % HTSIZE in [shard_begin, shard_end))
 };
 
-__device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, uint32_t &label)
+// One lane against one 128-byte line parked in LDS.  All key loads are issued before the
+// first compare (twelve dependent LDS round trips otherwise); the compares are one
+// v_cmp_eq_u64 each and the label is read only by lanes that matched.
+__device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, uint32_t &label,
+                                              uint32_t &hdr, uint32_t &extra_base)
 {
-    const uint64_t *keys = reinterpret_cast<const uint64_t *>(line);
+    const u32x4 *L4 = reinterpret_cast<const u32x4 *>(line);
+    u32x4 kv[MZ_CAP / 2];
+#pragma unroll
+    for (int t = 0; t < MZ_CAP / 2; t++) kv[t] = L4[t];
+    const uint2 tail = *reinterpret_cast<const uint2 *>(line + MZ_LINE - 8);      // header, extra base
+    hdr = tail.x;
+    extra_base = tail.y;
+    bool eq[MZ_CAP];
     bool hit = false;
 #pragma unroll
-    for (int e = 0; e < MZ_CAP; e++)
-        if (keys[e] == c) { hit = true; label = reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[e]; }
+    for (int e = 0; e < MZ_CAP; e++) {
+        const uint64_t key = (uint64_t)kv[e >> 1][2 * (e & 1)] | ((uint64_t)kv[e >> 1][2 * (e & 1) + 1] << 32);
+        eq[e] = key == c;
+        hit = hit || eq[e];
+    }
+    if (hit) {
+        uint32_t at = 0;
+#pragma unroll
+        for (int e = 1; e < MZ_CAP; e++) at = eq[e] ? (uint32_t)e : at;
+        label = reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[at];
+    }
     return hit;
 }
 
@@ -438,11 +458,10 @@ void mz_query_kernel(const MzArgs A)
                         for (int s = 0; s < MZ_NS; s++) {
                             if (active[s] && run[s] >= rb && run[s] < rb + MZ_RUNS) {
                                 const uint8_t *L = linebuf + (run[s] - rb) * MZ_LSTRIDE;
-                                hit[s] = mz_match_line(L, c[s], lab[s]);
-                                const uint32_t hdr = reinterpret_cast<const uint32_t *>(L)[30];
+                                uint32_t hdr, eb;
+                                hit[s] = mz_match_line(L, c[s], lab[s], hdr, eb);
                                 const uint32_t extra = hdr >> 8;
                                 if (!hit[s] && extra) {                       // rare: lines beyond the first
-                                    const uint32_t eb = reinterpret_cast<const uint32_t *>(L)[31];
                                     for (uint32_t e = 0; e < extra && !hit[s]; e++) {
                                         const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
                                         u32x4 xv[MZ_CAP / 2];
