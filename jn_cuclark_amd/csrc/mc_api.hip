@@ -186,18 +186,26 @@ int mz_build_passes(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
                        n_lines, d_count, d_cursor, (const uint32_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr);
     HIPCHK(hipGetLastError());
     const int g = (int)std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, 16384);
-    hipLaunchKernelGGL(mc::mz::mz_extra_count_kernel, dim3(g), dim3(256), 0, st, d_count, n_lines, d_extra);
+    Scope tmp;
+    uint32_t *d_max = nullptr, max_extra = 0;
+    TMP_MALLOC(tmp, d_max, 4);
+    HIPCHK(hipMemsetAsync(d_max, 0, 4, st));
+    hipLaunchKernelGGL(mc::mz::mz_extra_count_kernel, dim3(g), dim3(256), 0, st, d_count, n_lines, d_extra, d_max);
     HIPCHK(hipGetLastError());
     int rc = scan_u32_device(c, d_extra, n_lines, d_ebase, n_extra);
     if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(&max_extra, d_max, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (max_extra > 0xFFFFu)              // one minimizer shared by > 786 000 k-mers: use the direct table
+        return fail(MC_ENOMEM, "minimizer index: a line chain exceeds 65535 extra lines");
     const size_t ebytes = (size_t)(*n_extra ? *n_extra : 1) * mc::mz::MZ_LINE;
     if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess) return fail(MC_ENOMEM, "minimizer index: extra lines");
     HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
+    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(g), dim3(256), 0, st, d_extra, d_ebase, n_lines, c->d_mz_lines);
+    HIPCHK(hipGetLastError());
     hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
                        static_cast<const key_t *>(d_keys), d_labels, nb, shard_begin, c->htsize, d_koff, c->k, c->mz_m,
                        n_lines, d_count, d_cursor, d_ebase, c->d_mz_lines, c->d_mz_extra);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(g), dim3(256), 0, st, d_count, d_ebase, n_lines, c->d_mz_lines);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return MC_OK;
@@ -229,7 +237,7 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
 
     free_db(c);
     double per_line = 6.0;
-    if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 12.0) per_line = v; }
+    if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
     const uint64_t want = (uint64_t)((double)n_keys / per_line) + 1024;
     if (want >= 0xFFFFFFF0ull) return fail(MC_EINVAL, "minimizer index: too many lines");
     const uint32_t n_lines = (uint32_t)want;
@@ -262,7 +270,7 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     c->info.line_capacity = mc::mz::MZ_CAP;
     c->info.device_bytes = lbytes + n_extra * mc::mz::MZ_LINE;
     int occ = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::mz::mz_query_kernel, mc::BLOCK_THREADS, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::mz::mz_query_kernel<false>, mc::BLOCK_THREADS, 0));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
     if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
@@ -447,8 +455,10 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     if (c->d_mz_lines) {
         mc::mz::MzArgs m{};
         m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra; m.n_lines = c->mz_n_lines; m.m = c->mz_m;
-        m.sharded = (c->info.shard_begin != 0 || c->info.shard_end != c->htsize) ? 1u : 0u;
-        hipLaunchKernelGGL(mc::mz::mz_query_kernel, g, b, 0, st, m);
+        if (c->info.shard_begin != 0 || c->info.shard_end != c->htsize)
+            hipLaunchKernelGGL(mc::mz::mz_query_kernel<true>, g, b, 0, st, m);
+        else
+            hipLaunchKernelGGL(mc::mz::mz_query_kernel<false>, g, b, 0, st, m);
     } else if (!c->wide) {
         if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, false>), g, b, 0, st, a);
         else                          hipLaunchKernelGGL((mc::query_kernel<128, false>), g, b, 0, st, a);

@@ -48,7 +48,7 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x;
 }
 
-// minimizer length for a k-mer length (w = k - m + 1 windows, at most MZ_MAXW)
+// minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k > 12)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
 
 // Ordering key of a canonical m-mer: one 64-bit multiply-fold, of which the top 52 bits
@@ -108,6 +108,14 @@ __device__ __forceinline__ uint32_t line_of(uint64_t K, uint32_t n_lines)
     return __umulhi(h, n_lines);
 }
 
+// A line's header (dword 30) = number of extra lines (low 16 bits) | a 16-bit Bloom word over
+// the k-mers that live in those extra lines: a k-mer that is not in the first line follows the
+// chain only if its bit is set, so nearly every miss ends at the first line.
+__device__ __forceinline__ uint32_t extra_bit(uint64_t c)
+{
+    return 16u + ((((uint32_t)c ^ (uint32_t)(c >> 32)) * 0x9E3779B1u) >> 28);
+}
+
 // ---------------------------------------------------------------------------
 // index build from the raw bucket arrays (sizes u8, quotients, labels)
 // ---------------------------------------------------------------------------
@@ -144,6 +152,7 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
                     const uint32_t e = slot - MZ_CAP;
                     base = extra_lines + ((uint64_t)extra_base[l] + e / MZ_CAP) * MZ_LINE;
                     pos = e % MZ_CAP;
+                    atomicOr(reinterpret_cast<uint32_t *>(lines + (uint64_t)l * MZ_LINE) + 30, 1u << extra_bit(c));
                 }
                 reinterpret_cast<uint64_t *>(base)[pos] = c;
                 reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[pos] = labels[koff + j];
@@ -154,23 +163,26 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
 }
 
 // number of extra lines per line (for the scan) and, later, the headers
-__global__ void mz_extra_count_kernel(const uint32_t *count, uint32_t n_lines, uint32_t *extra)
+__global__ void mz_extra_count_kernel(const uint32_t *count, uint32_t n_lines, uint32_t *extra, uint32_t *max_extra)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
-        const uint32_t c = count[i];
-        extra[i] = c > (uint32_t)MZ_CAP ? (c - MZ_CAP + MZ_CAP - 1) / MZ_CAP : 0u;
-    }
-}
-
-__global__ void mz_header_kernel(const uint32_t *count, const uint32_t *extra_base, uint32_t n_lines, uint8_t *lines)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t mx = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
         const uint32_t c = count[i];
         const uint32_t ex = c > (uint32_t)MZ_CAP ? (c - MZ_CAP + MZ_CAP - 1) / MZ_CAP : 0u;
+        extra[i] = ex;
+        mx = ex > mx ? ex : mx;
+    }
+    if (mx) atomicMax(max_extra, mx);
+}
+
+// runs BEFORE the placing pass, which ORs the Bloom bits into dword 30
+__global__ void mz_header_kernel(const uint32_t *extra, const uint32_t *extra_base, uint32_t n_lines, uint8_t *lines)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
         uint32_t *hdr = reinterpret_cast<uint32_t *>(lines + i * MZ_LINE) + 30;
-        hdr[0] = (c < (uint32_t)MZ_CAP ? c : (uint32_t)MZ_CAP) | (ex << 8);
+        hdr[0] = extra[i];                  // <= 0xFFFF, checked by the host
         hdr[1] = extra_base[i];
     }
 }
@@ -210,7 +222,6 @@ struct MzArgs {
     const uint8_t *extra;      // extra lines
     uint32_t n_lines;
     uint32_t m;
-    uint32_t sharded;          // apply the bucket-range filter (r = c % HTSIZE in [shard_begin, shard_end))
 };
 
 // One lane against one 128-byte line parked in LDS.  All key loads are issued before the
@@ -226,26 +237,23 @@ __device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, u
     const uint2 tail = *reinterpret_cast<const uint2 *>(line + MZ_LINE - 8);      // header, extra base
     hdr = tail.x;
     extra_base = tail.y;
-    bool eq[MZ_CAP];
-    bool hit = false;
+    uint32_t at = MZ_CAP;
 #pragma unroll
     for (int e = 0; e < MZ_CAP; e++) {
         const uint64_t key = (uint64_t)kv[e >> 1][2 * (e & 1)] | ((uint64_t)kv[e >> 1][2 * (e & 1) + 1] << 32);
-        eq[e] = key == c;
-        hit = hit || eq[e];
+        at = key == c ? (uint32_t)e : at;
     }
-    if (hit) {
-        uint32_t at = 0;
-#pragma unroll
-        for (int e = 1; e < MZ_CAP; e++) at = eq[e] ? (uint32_t)e : at;
-        label = reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[at];
-    }
+    const bool hit = at != (uint32_t)MZ_CAP;
+    if (hit) label = reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[at];
     return hit;
 }
 
 #ifndef MC_MZ_MIN_WAVES
 #define MC_MZ_MIN_WAVES 5      // measured: 4 waves/SIMD 616, 5 waves (24 B of scratch) 695 Mreads/s
 #endif
+// SHARDED: apply the bucket-range filter of a shard (a separate instantiation keeps the
+// divider and the range out of the unsharded kernel's scalar registers).
+template <bool SHARDED>
 __global__ __launch_bounds__(BLOCK_THREADS, MC_MZ_MIN_WAVES)
 void mz_query_kernel(const MzArgs A)
 {
@@ -263,8 +271,7 @@ void mz_query_kernel(const MzArgs A)
     uint8_t *linebuf = s_line[wave];
 
     const uint32_t k = a.k, m = A.m;
-    const uint32_t W = k - m + 1;
-    const bool full_w = W == MZ_MAXW;          // always, with m = k - 12
+    constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - 12 (mmer_len), k >= 16
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
     const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
@@ -324,8 +331,8 @@ void mz_query_kernel(const MzArgs A)
                 const uint64_t *w = reinterpret_cast<const uint64_t *>(slice) + (j0 >> 2);
                 const uint64_t wa = w[0], wb = w[1];
                 const uint32_t b = 16u * (j0 & 3u) + 2u * (p & 7u);           // bit offset of the first base
-                const uint64_t top = (wa << b) | (b ? (wb >> (64u - b)) : 0ull);
-                return (top >> (64u - 2u * len)) & mask;
+                const uint64_t top = (wa << b) | ((wb >> 1) >> (63u - b));   // b in [0, 62]
+                return top >> (64u - 2u * len);                               // len bases: nothing left to mask
             }
             const uint32_t j0 = first + (p >> 3);
             const uint64_t hi = ((uint64_t)con(j0) << 48) | ((uint64_t)con(j0 + 1) << 32)
@@ -378,7 +385,7 @@ void mz_query_kernel(const MzArgs A)
                             rc = revcomp(x, k);
                             key = mmer_key2(x >> (2u * (k - m)), rc & mmask);      // first m bases, both strands
                             c[s] = x < rc ? x : rc;
-                            if (A.sharded) {
+                            if constexpr (SHARDED) {
                                 const uint64_t q = div_u64(c[s], a.div);
                                 const uint64_t r = c[s] - q * a.div.d;
                                 active[s] = (r >= a.shard_begin) && (r < a.shard_end);
@@ -407,13 +414,8 @@ void mz_query_kernel(const MzArgs A)
                         uint64_t K = MZ_KEY_NONE, v[MZ_MAXW];
 #pragma unroll
                         for (int i = 0; i < MZ_MAXW; i++) v[i] = keyv[64 * s + lane + i];
-                        if (full_w) {
 #pragma unroll
-                            for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, v[i]);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, (uint32_t)i < W ? v[i] : MZ_KEY_NONE);
-                        }
+                        for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, v[i]);
                         line[s] = active[s] ? line_of(K, A.n_lines) : 0xFFFFFFFFu;
                         // line of the lane before (DPP wave_shr:1); lane 0 sees the previous slot's last lane
                         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_last, (int)line[s], 0x138, 0xf, 0xf, false);
@@ -460,8 +462,8 @@ void mz_query_kernel(const MzArgs A)
                                 const uint8_t *L = linebuf + (run[s] - rb) * MZ_LSTRIDE;
                                 uint32_t hdr, eb;
                                 hit[s] = mz_match_line(L, c[s], lab[s], hdr, eb);
-                                const uint32_t extra = hdr >> 8;
-                                if (!hit[s] && extra) {                       // rare: lines beyond the first
+                                const uint32_t extra = hdr & 0xFFFFu;
+                                if (!hit[s] && extra && ((hdr >> extra_bit(c[s])) & 1u)) {   // rare: lines beyond the first
                                     for (uint32_t e = 0; e < extra && !hit[s]; e++) {
                                         const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
                                         u32x4 xv[MZ_CAP / 2];

@@ -334,3 +334,23 @@ def test_paired_250bp_reads_are_staged_in_pieces(gpu, oracle):
         got = db.classify(rp, con)
     assert np.array_equal(got, want)
     assert (want[:, 0] > 300).sum() > 500
+
+
+@pytest.mark.parametrize("fill", ["12", "40"])
+def test_minimizer_extra_line_chains(gpu, oracle, monkeypatch, fill, index_mode):
+    """crowded minimizer lines (MC_MZ_FILL k-mers per 12-slot line on average): most lookups
+    walk the extra-line chain, guarded by the header's Bloom word"""
+    if index_mode != "minimizer":
+        pytest.skip("minimizer index only")
+    monkeypatch.setenv("MC_MZ_FILL", fill)
+    genomes, sz, ky, lb = small_db()
+    names, seqs = mixed_fasta(genomes, K, n=1500)
+    _, rp, con = pack_with_oracle(oracle, synth.fasta_text(names, seqs, width=70), K)
+    odb = oracle.OracleDB.from_arrays(HT, sz, ky, lb)
+    want_rows, _ = odb.query_rows(K, rp, con, 15)
+    with _open(gpu, sz, ky, lb) as db:
+        got, rows = db.classify(rp, con, extended=True)
+        info = db.db_info()
+    assert info["n_overflow_buckets"] > 0          # extra lines exist
+    assert np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
