@@ -175,7 +175,7 @@ def main():
         bytes_per_read = 54.0 + kmers_per_read * (8.0 + 4.0 * nonempty + 2.0 * hr)
         achieved = bytes_per_read * n_reads / (kern_ms_avg * 1e-3) / 1e9
         index = "lines" if os.environ.get("MC_INDEX") == "lines" or info["line_bytes"] == 64 else "minimizer"
-        kernel_name = "mc::mz::mz_query_kernel" if index == "minimizer" else "mc::query_kernel<%d, false>" % info["line_bytes"]
+        kernel_name = ("mc::mz::mz_query_kernel<%s>" % ("true" if shard_mode else "false")) if index == "minimizer" else "mc::query_kernel<%d, false>" % info["line_bytes"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
