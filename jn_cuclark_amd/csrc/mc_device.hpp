@@ -287,7 +287,7 @@ void query_kernel(const QueryArgs a)
     __shared__ __attribute__((aligned(16))) uint16_t s_con[WAVES_PER_BLOCK][STAGE_CON + 16];
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar registers
     uint16_t *slice = s_con[wave];
 
     const uint32_t k = a.k;

@@ -264,7 +264,7 @@ void mz_query_kernel(const MzArgs A)
     __shared__ __attribute__((aligned(16))) uint8_t s_line[WAVES_PER_BLOCK][MZ_RUNS * MZ_LSTRIDE];
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar registers
     uint16_t *slice = s_con[wave];
     uint64_t *keyv = s_key[wave];
     uint32_t *runline = s_runline[wave];
@@ -351,80 +351,103 @@ void mz_query_kernel(const MzArgs A)
 
             uint32_t pp = beg;
             while (pp < end) {
-                const uint32_t plen = con(pp);
+                const uint32_t plen = (uint32_t)__builtin_amdgcn_readfirstlane((int)con(pp));   // same address in every lane
                 const uint32_t first = pp + 1;
                 pp = first + (plen ? (plen - 1u) / 8u + 1u : 0u);
                 if (plen < k) continue;
                 const uint32_t nk = plen - k + 1u;
-                const uint32_t nm = plen - m + 1u;           // m-mer start positions
 
                 for (uint32_t base = 0; base < nk; base += 64u * MZ_NS) {
-                    // (1) the k-mer of every lane and the keys of the m-mers starting at
-                    //     base .. base + 64*NS - 1 + W - 1 (m-mer p = the first m bases of k-mer p)
+                    // (1) lane l holds the two k-mers at positions base + 2l and base + 2l + 1: the second
+                    //     is the first shifted by one base (no second cut from LDS, no second reverse
+                    //     complement), and their two windows share 12 of 14 m-mer keys.  Keys of the
+                    //     m-mers at base .. base + 64*NS + W - 2 go to LDS (m-mer p = first m bases of k-mer p).
+                    static_assert(MZ_NS == 2, "two consecutive positions per lane");
                     bool     active[MZ_NS], leader[MZ_NS];
                     uint64_t c[MZ_NS];
                     uint32_t line[MZ_NS], run[MZ_NS];
-                    // the m-mers that start behind the part's last k-mer (positions nk .. nm-1) all
-                    // lie inside that k-mer: they are cut from its value, not re-read from LDS
                     const bool last_step = base + 64u * MZ_NS >= nk;                // wave-uniform
-                    const uint32_t last_slot = (nk - 1u - base) >> 6, last_lane = (nk - 1u - base) & 63u;
-                    uint64_t x_last = 0, rc_last = 0;
-                    auto tail_key = [&](uint32_t p) -> uint64_t {                   // nk <= p < nm
-                        const uint32_t i = p - (nk - 1u);
-                        return mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
-                    };
+                    const uint32_t p0 = base + 2u * lane;
+                    active[0] = p0 < nk;
+                    active[1] = p0 + 1u < nk;
+                    uint64_t x0 = 0, x1 = 0, rc0 = 0, rc1 = 0;
+                    uint64_t key0 = MZ_KEY_NONE, key1 = MZ_KEY_NONE;
+                    c[0] = 0; c[1] = 0;
+                    if (active[0]) {
+                        if constexpr (STAGED) {
+                            uint32_t j0 = first - c0a + (p0 >> 3);                    // container index in the slice
+                            if (j0 > (uint32_t)(STAGE_CON + 4)) j0 = (uint32_t)(STAGE_CON + 4);
+                            const uint64_t *w = reinterpret_cast<const uint64_t *>(slice) + (j0 >> 2);
+                            const uint64_t wa = w[0], wb = w[1];
+                            const uint32_t b = 16u * (j0 & 3u) + 2u * (p0 & 7u);      // bit offset of base p0: <= 60
+                            const uint64_t top = (wa << b) | ((wb >> 1) >> (63u - b)); // 32 bases from p0
+                            const uint64_t top1 = (top << 2) | ((wb >> (62u - b)) & 3ull);   // 32 bases from p0 + 1
+                            x0 = top >> (64u - 2u * k);
+                            x1 = top1 >> (64u - 2u * k);
+                        } else {
+                            x0 = bases_at(first, p0, k, kmask);
+                            x1 = bases_at(first, p0 + 1u, k, kmask);
+                        }
+                        rc0 = revcomp(x0, k);
+                        rc1 = (rc0 >> 2) | ((uint64_t)(3u - ((uint32_t)x1 & 3u)) << (2u * k - 2u));
+                        key0 = mmer_key2(x0 >> (2u * (k - m)), rc0 & mmask);        // first m bases, both strands
+                        c[0] = x0 < rc0 ? x0 : rc0;
+                        const uint64_t k1 = mmer_key2(x1 >> (2u * (k - m)), rc1 & mmask);
+                        key1 = active[1] ? k1 : MZ_KEY_NONE;
+                        c[1] = x1 < rc1 ? x1 : rc1;
+                        if constexpr (SHARDED) {
 #pragma unroll
-                    for (int s = 0; s < MZ_NS; s++) {
-                        const uint32_t p = base + 64u * s + lane;
-                        active[s] = p < nk;
-                        c[s] = 0;
-                        uint64_t key = MZ_KEY_NONE;
-                        uint64_t x = 0, rc = 0;
-                        if (active[s]) {
-                            x = bases_at(first, p, k, kmask);
-                            rc = revcomp(x, k);
-                            key = mmer_key2(x >> (2u * (k - m)), rc & mmask);      // first m bases, both strands
-                            c[s] = x < rc ? x : rc;
-                            if constexpr (SHARDED) {
+                            for (int s = 0; s < MZ_NS; s++) {
                                 const uint64_t q = div_u64(c[s], a.div);
                                 const uint64_t r = c[s] - q * a.div.d;
-                                active[s] = (r >= a.shard_begin) && (r < a.shard_end);
+                                active[s] = active[s] && (r >= a.shard_begin) && (r < a.shard_end);
                             }
                         }
-                        if (last_step && (uint32_t)s == last_slot) {
-                            x_last = lane_bcast64(x, last_lane);
-                            rc_last = lane_bcast64(rc, last_lane);
-                        }
-                        if (p >= nk && p < nm) key = tail_key(p);
-                        keyv[64 * s + lane] = key;
+                    }
+                    {
+                        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u64x2 *>(keyv + 2u * lane) = u64x2{key0, key1};
+                    }
+                    // the W-1 m-mers that start behind the part's last k-mer (positions nk .. nk+W-2) all
+                    // lie inside that k-mer: cut from its value, stored on top of the stores above
+                    const uint32_t q = nk - 1u - base;                               // last k-mer: lane q/2, half q%2
+                    uint64_t x_last = 0, rc_last = 0;
+                    if (last_step) {                                                 // every lane takes part in the select
+                        x_last = lane_bcast64((q & 1u) ? x1 : x0, q >> 1);
+                        rc_last = lane_bcast64((q & 1u) ? rc1 : rc0, q >> 1);
                     }
                     if (lane < W - 1u) {
-                        const uint32_t p2 = base + 64u * MZ_NS + lane;
-                        uint64_t key = MZ_KEY_NONE;
-                        if (p2 < nm) key = last_step ? tail_key(p2) : mmer_key(bases_at(first, p2, m, mmask), m);
-                        keyv[64 * MZ_NS + lane] = key;
+                        if (last_step) {
+                            const uint32_t i = lane + 1u;
+                            keyv[64 * MZ_NS + lane] = MZ_KEY_NONE;
+                            keyv[q + i] = mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
+                        } else {
+                            keyv[64 * MZ_NS + lane] = mmer_key(bases_at(first, base + 64u * MZ_NS + lane, m, mmask), m);
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     // (2) minimizer key = window minimum, (3) line, (4) runs of equal lines
-                    uint32_t n_runs = 0, prev_last = 0xFFFFFFFFu;
-                    const uint64_t le_mask = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+                    uint32_t n_runs;
+                    {
+                        uint64_t v[MZ_MAXW + 1];
 #pragma unroll
-                    for (int s = 0; s < MZ_NS; s++) {
-                        uint64_t K = MZ_KEY_NONE, v[MZ_MAXW];
+                        for (int i = 0; i < MZ_MAXW + 1; i++) v[i] = keyv[2u * lane + i];
+                        uint64_t mid = v[1];
 #pragma unroll
-                        for (int i = 0; i < MZ_MAXW; i++) v[i] = keyv[64 * s + lane + i];
-#pragma unroll
-                        for (int i = 0; i < MZ_MAXW; i++) K = key_min(K, v[i]);
-                        line[s] = active[s] ? line_of(K, A.n_lines) : 0xFFFFFFFFu;
-                        // line of the lane before (DPP wave_shr:1); lane 0 sees the previous slot's last lane
-                        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_last, (int)line[s], 0x138, 0xf, 0xf, false);
-                        prev_last = (uint32_t)__builtin_amdgcn_readlane((int)line[s], 63);
-                        leader[s] = active[s] && line[s] != prev;
-                        const uint64_t lead_mask = __ballot(leader[s]);
-                        // a run continuing from the previous slot keeps that slot's last run index
-                        run[s] = n_runs + (uint32_t)__popcll(lead_mask & le_mask) - 1u;
-                        n_runs += (uint32_t)__popcll(lead_mask);
+                        for (int i = 2; i < MZ_MAXW; i++) mid = key_min(mid, v[i]);
+                        const uint64_t K0 = key_min(v[0], mid), K1 = key_min(mid, v[MZ_MAXW]);
+                        line[0] = active[0] ? line_of(K0, A.n_lines) : 0xFFFFFFFFu;
+                        line[1] = active[1] ? line_of(K1, A.n_lines) : 0xFFFFFFFFu;
+                        // second line of the lane before (DPP wave_shr:1); nothing before lane 0
+                        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)line[1], 0x138, 0xf, 0xf, false);
+                        leader[0] = active[0] && line[0] != prev;
+                        leader[1] = active[1] && line[1] != line[0];
+                        const uint64_t b0 = __ballot(leader[0]), b1 = __ballot(leader[1]);
+                        const uint64_t lt_mask = (1ull << lane) - 1ull;
+                        run[0] = (uint32_t)__popcll(b0 & lt_mask) + (uint32_t)__popcll(b1 & lt_mask) + (leader[0] ? 1u : 0u) - 1u;
+                        run[1] = run[0] + (leader[1] ? 1u : 0u);
+                        n_runs = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
                     }
 
                     bool     hit[MZ_NS];
