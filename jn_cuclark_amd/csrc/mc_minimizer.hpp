@@ -84,6 +84,15 @@ __device__ __forceinline__ uint64_t mmer_key2(uint64_t w, uint64_t rcw)
     return MZ_KEY_ONE | (z >> 12);
 }
 
+// A copy of a per-lane value the compiler cannot trace back: what is derived from it is computed
+// where it is used instead of being hoisted out of every loop into long-lived registers
+// (this kernel is bound by its register budget: 5 vs 6 waves per SIMD).
+__device__ __forceinline__ uint32_t opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, uint32_t uniform_lane)
 {
     return (uint64_t)lane_bcast((uint32_t)v, uniform_lane) | ((uint64_t)lane_bcast((uint32_t)(v >> 32), uniform_lane) << 32);
@@ -248,9 +257,25 @@ __device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, u
     return hit;
 }
 
+// Occupancy is what this kernel lives on (measured on the headline workload, after the register
+// diet: 5 waves/SIMD 934, 6 waves 1022, 7 waves 1047, 8 waves with 48 B of scratch 977 Mreads/s):
+// <= 72 VGPRs and <= 5760 bytes of LDS per wave give 7 workgroups per CU (5792 bytes already
+// drop one: 776 Mreads/s).
 #ifndef MC_MZ_MIN_WAVES
-#define MC_MZ_MIN_WAVES 5      // measured: 4 waves/SIMD 616, 5 waves (24 B of scratch) 695 Mreads/s
+#define MC_MZ_MIN_WAVES 7
 #endif
+#ifndef MC_MZ_STAGE_CON
+#define MC_MZ_STAGE_CON 448    // u16 containers of a read group staged per wave (16 reads x 150 bp = 320)
+#endif
+static constexpr int MZ_STAGE_CON = MC_MZ_STAGE_CON;
+// per-wave LDS: staged containers | line index of each run | parked lines; the m-mer keys of a
+// step (dead once the window minima are taken) share the space of the parked lines
+static constexpr int MZ_LDS_SLICE = (MZ_STAGE_CON + 16) * 2;
+static constexpr int MZ_LDS_RUNLINE = MZ_LDS_SLICE;
+static constexpr int MZ_LDS_LINES = MZ_LDS_RUNLINE + MZ_RUNS * 4;
+static constexpr int MZ_LDS_KEYS_BYTES = (64 * MZ_NS + MZ_MAXW + 3) * 8;
+static constexpr int MZ_LDS_WAVE = MZ_LDS_LINES + (MZ_RUNS * MZ_LSTRIDE > MZ_LDS_KEYS_BYTES ? MZ_RUNS * MZ_LSTRIDE : MZ_LDS_KEYS_BYTES);
+static_assert(MZ_LDS_LINES % 16 == 0 && MZ_LDS_WAVE % 16 == 0, "16-byte aligned LDS regions");
 // SHARDED: apply the bucket-range filter of a shard (a separate instantiation keeps the
 // divider and the range out of the unsharded kernel's scalar registers).
 template <bool SHARDED>
@@ -258,17 +283,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, MC_MZ_MIN_WAVES)
 void mz_query_kernel(const MzArgs A)
 {
     const QueryArgs &a = A.q;
-    __shared__ __attribute__((aligned(16))) uint16_t s_con[WAVES_PER_BLOCK][STAGE_CON + 16];
-    __shared__ __attribute__((aligned(16))) uint64_t s_key[WAVES_PER_BLOCK][64 * MZ_NS + MZ_MAXW + 3];
-    __shared__ uint32_t s_runline[WAVES_PER_BLOCK][MZ_RUNS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_line[WAVES_PER_BLOCK][MZ_RUNS * MZ_LSTRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[WAVES_PER_BLOCK][MZ_LDS_WAVE];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar registers
-    uint16_t *slice = s_con[wave];
-    uint64_t *keyv = s_key[wave];
-    uint32_t *runline = s_runline[wave];
-    uint8_t *linebuf = s_line[wave];
+    uint16_t *slice = reinterpret_cast<uint16_t *>(s_mem[wave]);
+    uint32_t *runline = reinterpret_cast<uint32_t *>(s_mem[wave] + MZ_LDS_RUNLINE);
+    uint8_t *linebuf = s_mem[wave] + MZ_LDS_LINES;
+    uint64_t *keyv = reinterpret_cast<uint64_t *>(linebuf);     // aliases the parked lines (see above)
 
     const uint32_t k = a.k, m = A.m;
     constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - 12 (mmer_len), k >= 16
@@ -289,7 +311,7 @@ void mz_query_kernel(const MzArgs A)
         for (uint32_t rs = 0; rs < nr;) {
         const uint32_t c0 = lane_bcast(ptr_v, rs);
         const uint32_t c0a = c0 & ~7u;
-        const uint64_t fits = __ballot(lane > rs && lane <= nr && (ptr_v - c0a) <= (uint32_t)STAGE_CON);
+        const uint64_t fits = __ballot(lane > rs && lane <= nr && (ptr_v - c0a) <= (uint32_t)MZ_STAGE_CON);
         const bool staged = a.stage_ok && fits != 0;
         const uint32_t re = staged ? (uint32_t)(63 - __builtin_clzll((unsigned long long)fits)) : rs + 1u;
         const uint32_t c1 = lane_bcast(ptr_v, re);
@@ -317,7 +339,7 @@ void mz_query_kernel(const MzArgs A)
         auto con = [&](uint32_t i) -> uint32_t {
             if constexpr (STAGED) {
                 const uint32_t li = i - c0a;
-                return slice[(li < (uint32_t)(STAGE_CON + 12) ? li : (uint32_t)(STAGE_CON + 12)) ^ 3u];
+                return slice[(li < (uint32_t)(MZ_STAGE_CON + 12) ? li : (uint32_t)(MZ_STAGE_CON + 12)) ^ 3u];
             } else {
                 const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
                 return a.containers[ii];
@@ -327,7 +349,7 @@ void mz_query_kernel(const MzArgs A)
         auto bases_at = [&](uint32_t first, uint32_t p, uint32_t len, uint64_t mask) -> uint64_t {
             if constexpr (STAGED) {
                 uint32_t j0 = first - c0a + (p >> 3);                         // container index in the slice
-                if (j0 > (uint32_t)(STAGE_CON + 4)) j0 = (uint32_t)(STAGE_CON + 4);
+                if (j0 > (uint32_t)(MZ_STAGE_CON + 4)) j0 = (uint32_t)(MZ_STAGE_CON + 4);
                 const uint64_t *w = reinterpret_cast<const uint64_t *>(slice) + (j0 >> 2);
                 const uint64_t wa = w[0], wb = w[1];
                 const uint32_t b = 16u * (j0 & 3u) + 2u * (p & 7u);           // bit offset of the first base
@@ -376,7 +398,7 @@ void mz_query_kernel(const MzArgs A)
                     if (active[0]) {
                         if constexpr (STAGED) {
                             uint32_t j0 = first - c0a + (p0 >> 3);                    // container index in the slice
-                            if (j0 > (uint32_t)(STAGE_CON + 4)) j0 = (uint32_t)(STAGE_CON + 4);
+                            if (j0 > (uint32_t)(MZ_STAGE_CON + 4)) j0 = (uint32_t)(MZ_STAGE_CON + 4);
                             const uint64_t *w = reinterpret_cast<const uint64_t *>(slice) + (j0 >> 2);
                             const uint64_t wa = w[0], wb = w[1];
                             const uint32_t b = 16u * (j0 & 3u) + 2u * (p0 & 7u);      // bit offset of base p0: <= 60
@@ -417,12 +439,13 @@ void mz_query_kernel(const MzArgs A)
                         rc_last = lane_bcast64((q & 1u) ? rc1 : rc0, q >> 1);
                     }
                     if (lane < W - 1u) {
+                        const uint32_t ln = opaque(lane);
                         if (last_step) {
-                            const uint32_t i = lane + 1u;
-                            keyv[64 * MZ_NS + lane] = MZ_KEY_NONE;
+                            const uint32_t i = ln + 1u;
+                            keyv[64 * MZ_NS + ln] = MZ_KEY_NONE;
                             keyv[q + i] = mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
                         } else {
-                            keyv[64 * MZ_NS + lane] = mmer_key(bases_at(first, base + 64u * MZ_NS + lane, m, mmask), m);
+                            keyv[64 * MZ_NS + ln] = mmer_key(bases_at(first, base + 64u * MZ_NS + ln, m, mmask), m);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -444,8 +467,10 @@ void mz_query_kernel(const MzArgs A)
                         leader[0] = active[0] && line[0] != prev;
                         leader[1] = active[1] && line[1] != line[0];
                         const uint64_t b0 = __ballot(leader[0]), b1 = __ballot(leader[1]);
-                        const uint64_t lt_mask = (1ull << lane) - 1ull;
-                        run[0] = (uint32_t)__popcll(b0 & lt_mask) + (uint32_t)__popcll(b1 & lt_mask) + (leader[0] ? 1u : 0u) - 1u;
+                        // leaders in lower lanes (v_mbcnt) = index of this lane's first run
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
+                                             + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                        run[0] = below + (leader[0] ? 1u : 0u) - 1u;
                         run[1] = run[0] + (leader[1] ? 1u : 0u);
                         n_runs = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
                     }
@@ -463,19 +488,20 @@ void mz_query_kernel(const MzArgs A)
                         const uint32_t nb = n_runs - rb < (uint32_t)MZ_RUNS ? n_runs - rb : (uint32_t)MZ_RUNS;
                         // 8 lanes fetch one 128-byte line; MZ_RUNS/8 rounds, all issued before use
                         u32x4 v[MZ_RUNS / 8];
+                        const uint32_t lf = opaque(lane);
 #pragma unroll
                         for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
-                            const uint32_t j = 8u * rd + (lane >> 3);
+                            const uint32_t j = 8u * rd + (lf >> 3);
                             v[rd] = u32x4{~0u, ~0u, ~0u, ~0u};
                             if (j < nb) {
-                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)runline[j] * MZ_LINE) + (lane & 7u);
+                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)runline[j] * MZ_LINE) + (lf & 7u);
                                 v[rd] = __builtin_nontemporal_load(src);
                             }
                         }
 #pragma unroll
                         for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
-                            const uint32_t j = 8u * rd + (lane >> 3);
-                            if (j < nb) *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lane & 7u) * 16u) = v[rd];
+                            const uint32_t j = 8u * rd + (lf >> 3);
+                            if (j < nb) *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lf & 7u) * 16u) = v[rd];
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
@@ -585,7 +611,8 @@ void mz_query_kernel(const MzArgs A)
                     sum = wave_sum_u32(valid ? acc_c : 0u);
                 }
                 uint32_t out = 0;
-                switch (lane) {
+                const uint32_t lo = opaque(lane);
+                switch (lo) {
                 case 0: out = sum & 0xFFFFu; break;
                 case 1: out = k1 ? (0xFFFFu - (k1 & 0xFFFFu)) + 1u : 0u; break;
                 case 2: out = k1 >> 16; break;
@@ -593,7 +620,7 @@ void mz_query_kernel(const MzArgs A)
                 case 4: out = k2 >> 16; break;
                 default: break;
                 }
-                if (lane < 5u) a.final_rows[rd * 5u + lane] = (uint16_t)out;
+                if (lo < 5u) a.final_rows[rd * 5u + lo] = (uint16_t)out;
             }
         }
         };   // run_group
