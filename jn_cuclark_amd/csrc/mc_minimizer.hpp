@@ -304,7 +304,10 @@ void mz_query_kernel(const MzArgs A)
         const uint64_t r0 = g * GROUP_READS;
         const uint32_t nr = (uint32_t)((a.n_reads - r0) < GROUP_READS ? (a.n_reads - r0) : GROUP_READS);
         uint32_t ptr_v = 0;
-        if (lane <= nr) ptr_v = a.reads_ptr[r0 + lane];
+        {
+            const uint32_t lg = opaque(lane);
+            if (lg <= nr) ptr_v = a.reads_ptr[r0 + lg];
+        }
         // The group is staged into the wave's LDS slice in as few pieces as fit: usually all
         // 16 reads at once; long reads (2 x 250 bp pairs, contigs) in smaller pieces; a single
         // read larger than the slice is read from global memory.
@@ -316,7 +319,7 @@ void mz_query_kernel(const MzArgs A)
         const uint32_t re = staged ? (uint32_t)(63 - __builtin_clzll((unsigned long long)fits)) : rs + 1u;
         const uint32_t c1 = lane_bcast(ptr_v, re);
         if (staged) {
-            for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
+            for (uint32_t j = opaque(lane) * 8u; c0a + j < c1; j += 64u * 8u) {
                 const uint64_t gi = (uint64_t)c0a + j;
                 // the slice holds the containers as big-endian 64-bit words (4 containers each,
                 // first base in the top bits): container i lives at u16 index i ^ 3, and any
@@ -356,6 +359,7 @@ void mz_query_kernel(const MzArgs A)
                 const uint64_t top = (wa << b) | ((wb >> 1) >> (63u - b));   // b in [0, 62]
                 return top >> (64u - 2u * len);                               // len bases: nothing left to mask
             }
+            p = opaque(p);          // rare path: keep its shift amounts out of the long-lived registers
             const uint32_t j0 = first + (p >> 3);
             const uint64_t hi = ((uint64_t)con(j0) << 48) | ((uint64_t)con(j0 + 1) << 32)
                               | ((uint64_t)con(j0 + 2) << 16) | (uint64_t)con(j0 + 3);
