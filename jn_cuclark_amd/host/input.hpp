@@ -1,0 +1,188 @@
+// Input images for the host driver: a read file as one contiguous byte range, whatever it is on disk.
+//
+//  * plain FASTA/FASTQ: mmap, as the reference does (src/CuCLARK_hh.hh:1339-1352);
+//  * gzip (magic 1f 8b, also concatenated members): inflated in memory with zlib -- the reference leaves
+//    this to its wrapper, which copies the file and runs gunzip on the copy
+//    (scripts/classify_metagenome.sh:118-137);
+//  * paired FASTQ: the mates are joined in memory into the FASTA records ">id\nR1NR2" that the reference
+//    writes to a temporary "<file1>_ConcatenatedByCLARK.fa" first (mergePairedFiles, src/file.cc:205-268).
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace host {
+
+class InputImage {
+public:
+    InputImage() = default;
+    InputImage(const InputImage &) = delete;
+    InputImage &operator=(const InputImage &) = delete;
+    ~InputImage() { release(); }
+
+    const uint8_t *data() const { return data_; }
+    size_t size() const { return size_; }
+    bool gzipped() const { return gz_; }
+
+    // false + err on failure; an empty file is a failure (as in the reference's size check)
+    bool load(const char *path, std::string &err)
+    {
+        release();
+        fd_ = open(path, O_RDONLY);
+        struct stat st;
+        if (fd_ == -1 || fstat(fd_, &st) != 0 || st.st_size == 0) {
+            err = std::string("Failed to open ") + path;
+            release();
+            return false;
+        }
+        map_len_ = (size_t)st.st_size;
+        map_ = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (map_ == MAP_FAILED) { map_ = nullptr; err = "Failed to mmapping the file."; release(); return false; }
+        const uint8_t *m = static_cast<const uint8_t *>(map_);
+        if (map_len_ >= 2 && m[0] == 0x1f && m[1] == 0x8b) {
+            gz_ = true;
+            if (!inflate_all(m, map_len_, own_, err)) { release(); return false; }
+            munmap(map_, map_len_); map_ = nullptr;
+            close(fd_); fd_ = -1;
+            data_ = own_.data(); size_ = own_.size();
+            if (size_ == 0) { err = std::string("Failed to open ") + path; return false; }
+        } else {
+            data_ = m; size_ = map_len_;
+        }
+        return true;
+    }
+
+    // take over a buffer built in memory (paired mates)
+    void adopt(std::vector<uint8_t> &&buf)
+    {
+        release();
+        own_ = std::move(buf);
+        data_ = own_.data(); size_ = own_.size();
+    }
+
+private:
+    void release()
+    {
+        if (map_) munmap(map_, map_len_);
+        if (fd_ != -1) close(fd_);
+        map_ = nullptr; fd_ = -1; map_len_ = 0; data_ = nullptr; size_ = 0; gz_ = false;
+        std::vector<uint8_t>().swap(own_);
+    }
+
+    static bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)
+    {
+        z_stream z;
+        std::memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, 15 + 16) != Z_OK) { err = "zlib: inflateInit2 failed"; return false; }
+        out.clear();
+        out.reserve(n * 4);
+        std::vector<uint8_t> chunk(8u << 20);
+        size_t pos = 0;
+        bool ended = false;                     // the current member is complete
+        z.next_in = const_cast<Bytef *>(src);
+        z.avail_in = 0;
+        for (;;) {
+            if (z.avail_in == 0) {              // avail_in is 32 bits wide: feed the input in pieces
+                if (pos >= n) break;
+                const size_t piece = std::min<size_t>(n - pos, (size_t)1 << 30);
+                z.next_in = const_cast<Bytef *>(src + pos);
+                z.avail_in = (uInt)piece;
+                pos += piece;
+            }
+            z.next_out = chunk.data();
+            z.avail_out = (uInt)chunk.size();
+            const int rc = inflate(&z, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
+                err = std::string("zlib: corrupt gzip input (") + (z.msg ? z.msg : "?") + ")";
+                inflateEnd(&z);
+                return false;
+            }
+            out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - z.avail_out));
+            if (rc == Z_STREAM_END) {
+                ended = true;
+                if (z.avail_in == 0 && pos >= n) break;
+                // another member may follow (bgzip, cat a.gz b.gz); anything else is trailing garbage
+                if (z.avail_in >= 2 && !(z.next_in[0] == 0x1f && z.next_in[1] == 0x8b)) break;
+                if (inflateReset(&z) != Z_OK) { err = "zlib: inflateReset failed"; inflateEnd(&z); return false; }
+                ended = false;
+            }
+        }
+        inflateEnd(&z);
+        if (!ended) { err = "zlib: truncated gzip input"; return false; }
+        return true;
+    }
+
+    const uint8_t *data_ = nullptr;
+    size_t size_ = 0;
+    void *map_ = nullptr;
+    size_t map_len_ = 0;
+    int fd_ = -1;
+    bool gz_ = false;
+    std::vector<uint8_t> own_;
+};
+
+// FASTQ mates -> FASTA records ">id\nR1NR2" in memory (reference mergePairedFiles, src/file.cc:205-268: ids
+// must match after cutting at ' ', '/', '\t', '@'; same messages).
+inline bool merge_paired(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, std::vector<uint8_t> &out,
+                         std::string &err)
+{
+    struct Lines {
+        const uint8_t *p, *end;
+        bool next(const uint8_t *&s, size_t &n)              // std::getline semantics
+        {
+            if (p >= end) return false;
+            const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(end - p)));
+            s = p;
+            n = (size_t)((nl ? nl : end) - p);
+            p = nl ? nl + 1 : end;
+            return true;
+        }
+    } A{a, a + na}, B{b, b + nb};
+    auto id_of = [](const uint8_t *l, size_t n, const uint8_t *&s, size_t &len) {
+        auto sep = [](uint8_t c) { return c == ' ' || c == '/' || c == '\t' || c == '@'; };
+        size_t i = 0;
+        while (i < n && sep(l[i])) i++;
+        size_t e = i;
+        while (e < n && !sep(l[e])) e++;
+        s = l + i; len = e - i;
+    };
+    out.clear();
+    out.reserve(na / 2 + nb / 2 + 1024);
+    const uint8_t *l1, *l2;
+    size_t n1, n2;
+    bool first = true;
+    while (A.next(l1, n1) && B.next(l2, n2)) {
+        if (first) {
+            first = false;
+            if (n1 == 0 || n2 == 0 || l1[0] != l2[0]) { err = "Error: the files have different format!"; return false; }
+            if (l1[0] != '@') { err = "Error: paired-end reads must be FASTQ files!"; return false; }
+        }
+        if (n1 == 0 || n2 == 0 || l1[0] != '@' || l2[0] != '@') continue;
+        const uint8_t *i1, *i2;
+        size_t k1, k2;
+        id_of(l1, n1, i1, k1);
+        id_of(l2, n2, i2, k2);
+        if (k1 != k2 || std::memcmp(i1, i2, k1) != 0) { err = "Error: read id does not match between files!"; return false; }
+        out.push_back('>');
+        out.insert(out.end(), i1, i1 + k1);
+        out.push_back('\n');
+        if (!(A.next(l1, n1) && B.next(l2, n2))) { err = "Error: Found read without sequence"; return false; }
+        out.insert(out.end(), l1, l1 + n1);
+        out.push_back('N');
+        out.insert(out.end(), l2, l2 + n2);
+        out.push_back('\n');
+        A.next(l1, n1); B.next(l2, n2);     // '+'
+        A.next(l1, n1); B.next(l2, n2);     // quality
+    }
+    return true;
+}
+
+} // namespace host

@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "dbbuild.hpp"
 #include "reads.hpp"
+#include "input.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -139,15 +140,31 @@ struct Classifier {
     void run_simple(const char *objects, const char *result)
     {
         std::cerr << "Classifying: " << objects << "\n";
-        struct stat st;
-        const int fd = open(objects, O_RDONLY);
-        if (fd == -1 || fstat(fd, &st) != 0 || st.st_size == 0) { std::cerr << "Failed to open " << objects << std::endl; if (fd != -1) close(fd); return; }
-        const size_t nb = (size_t)st.st_size;
-        const uint8_t *map = (const uint8_t *)mmap(nullptr, nb, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (map == MAP_FAILED) { close(fd); std::cerr << "Failed to mmapping the file." << std::endl; return; }
+        InputImage img;                 // mmap, or inflated in memory when the file is gzip
+        std::string ierr;
+        if (!img.load(objects, ierr)) { std::cerr << ierr << std::endl; return; }
+        run_image(img.data(), img.size(), result);
+    }
+
+    // paired FASTQ mates, joined in memory (the reference goes through a temporary FASTA file)
+    void run_paired(const char *f1, const char *f2, const char *result)
+    {
+        std::cerr << "Classifying: " << f1 << " + " << f2 << "\n";
+        InputImage a, b, joined;
+        std::string err;
+        if (!a.load(f1, err) || !b.load(f2, err)) { std::cerr << err << std::endl; std::exit(1); }
+        std::vector<uint8_t> buf;
+        if (!merge_paired(a.data(), a.size(), b.data(), b.size(), buf, err)) { perror(err.c_str()); std::exit(1); }   // as file.cc:220-259
+        if (buf.empty()) { std::cerr << "Failed to open " << f1 << std::endl; return; }
+        joined.adopt(std::move(buf));
+        run_image(joined.data(), joined.size(), result);
+    }
+
+    void run_image(const uint8_t *map, size_t nb, const char *result)
+    {
         const std::string csv = std::string(result) + ".csv";
         FILE *fout = std::fopen(csv.c_str(), "w");
-        if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; munmap((void *)map, nb); close(fd); return; }
+        if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
 
         struct timeval t0, t1;
         gettimeofday(&t0, nullptr);
@@ -287,8 +304,6 @@ struct Classifier {
         std::snprintf(buf, sizeof buf, "Done in %.1fs (%zu reads/min, %zu reads)\n", diff,
                       (size_t)(((double)n_objects) / diff * 60.0), n_objects);
         std::cerr << buf << "Results: " << csv << "\n";
-        munmap((void *)map, nb);
-        close(fd);
     }
 
     static bool looks_like_sequence_file(const char *path)
@@ -296,6 +311,7 @@ struct Classifier {
         std::ifstream f(path);
         std::string line;
         std::getline(f, line);
+        if (line.size() >= 2 && (unsigned char)line[0] == 0x1f && (unsigned char)line[1] == 0x8b) return true;   // gzip
         if (!line.empty() && (line[0] == '>' || line[0] == '@')) return true;
         return split_line(line, 4).size() == 2;     // reference run(): "ele.size() == 2"
     }
@@ -312,13 +328,7 @@ struct Classifier {
             return;
         }
         paired = true;
-        auto one = [&](const char *f1, const char *f2, const char *res) {
-            const std::string merged = std::string(f1) + "_ConcatenatedByCLARK.fa";
-            std::string err;
-            if (!merge_paired(f1, f2, merged.c_str(), err)) { perror(err.c_str()); std::exit(1); }
-            run_simple(merged.c_str(), res);
-            std::remove(merged.c_str());
-        };
+        auto one = [&](const char *f1, const char *f2, const char *res) { run_paired(f1, f2, res); };
         if (!file_readable(opt.results) || looks_like_sequence_file(opt.objects)) { one(opt.objects, opt.objects2, opt.results); return; }
         std::ifstream o1(opt.objects), o2(opt.objects2), r(opt.results);
         std::string a, b, rl;

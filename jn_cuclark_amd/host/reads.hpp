@@ -203,37 +203,4 @@ inline size_t pack_reads(const uint8_t *t, const ReadIndex &R, size_t r0, size_t
     return count;
 }
 
-// FASTQ mates -> FASTA records ">id\nR1NR2" (reference mergePairedFiles, src/file.cc:205-268;
-// ids must match after cutting at ' ', '/', '\t', '@').
-inline bool merge_paired(const char *f1, const char *f2, const char *out, std::string &err)
-{
-    std::ifstream a(f1), b(f2);
-    if (!a || !b) { err = "Failed to open paired files"; return false; }
-    std::ofstream o(out, std::ios::binary);
-    std::string l1, l2;
-    auto id_of = [](const std::string &l) {
-        size_t s = 0;
-        while (s < l.size() && (l[s] == ' ' || l[s] == '/' || l[s] == '\t' || l[s] == '@')) s++;
-        size_t e = s;
-        while (e < l.size() && l[e] != ' ' && l[e] != '/' && l[e] != '\t' && l[e] != '@') e++;
-        return l.substr(s, e - s);
-    };
-    bool first = true;
-    while (std::getline(a, l1) && std::getline(b, l2)) {
-        if (first) {
-            first = false;
-            if (l1.empty() || l2.empty() || l1[0] != l2[0]) { err = "Error: the files have different format!"; return false; }
-            if (l1[0] != '@') { err = "Error: paired-end reads must be FASTQ files!"; return false; }
-        }
-        if (l1.empty() || l2.empty() || l1[0] != '@' || l2[0] != '@') continue;
-        if (id_of(l1) != id_of(l2)) { err = "Error: read id does not match between files!"; return false; }
-        o << ">" << id_of(l1) << "\n";
-        if (!(std::getline(a, l1) && std::getline(b, l2))) { err = "Error: Found read without sequence"; return false; }
-        o << l1 << "N" << l2 << "\n";
-        std::getline(a, l1); std::getline(b, l2);     // '+'
-        std::getline(a, l1); std::getline(b, l2);     // quality
-    }
-    return true;
-}
-
 } // namespace host

@@ -132,8 +132,11 @@ def _expected_csv(oracle, text, k, ht, base, names, paired=False, extended=False
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fasta", "fastq_batches", "paired", "extended"])
+@pytest.mark.parametrize("mode", ["fasta", "fastq_batches", "paired", "extended", "fastq_gz", "paired_gz"])
 def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
+    """file -> CSV through bin/cuCLARK-l; the *_gz modes feed gzip files directly (inflated in memory; the
+    reference's wrapper script gunzips a copy first), paired mates are joined in memory"""
+    import gzip
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import mixed_fasta
@@ -146,20 +149,28 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
     dbdir.mkdir()
     names, seqs = mixed_fasta(genomes, k, seed=13, n=1500)
     args = ["-T", targets, "-D", str(dbdir), "-R", str(tmp_path / "res"), "--dump-batches", str(tmp_path / "dump.bin")]
-    paired = mode == "paired"
+    paired = mode in ("paired", "paired_gz")
     if paired:
         m1 = [s[:100].replace(b"\n", b"") for s in seqs]
         m2 = [s[50:150] for s in seqs]
         nm = [n.split(b" ")[0] for n in names]
         f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
-        f1.write_bytes(synth.fastq_text([n + b"/1" for n in nm], m1))
-        f2.write_bytes(synth.fastq_text([n + b"/2" for n in nm], m2))
+        t1, t2 = synth.fastq_text([n + b"/1" for n in nm], m1), synth.fastq_text([n + b"/2" for n in nm], m2)
+        if mode == "paired_gz":
+            f1, f2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+            f1.write_bytes(gzip.compress(t1))
+            # two concatenated gzip members (what `cat a.gz b.gz` or bgzip produce)
+            cut = t2.index(b"\n@", len(t2) // 2) + 1
+            f2.write_bytes(gzip.compress(t2[:cut]) + gzip.compress(t2[cut:]))
+        else:
+            f1.write_bytes(t1)
+            f2.write_bytes(t2)
         args += ["-P", str(f1), str(f2)]
         text = synth.fasta_text(nm, [a + b"N" + b for a, b in zip(m1, m2)])
-    elif mode == "fastq_batches":
+    elif mode in ("fastq_batches", "fastq_gz"):
         text = synth.fastq_text(names, seqs)
-        p = tmp_path / "reads.fq"
-        p.write_bytes(text)
+        p = tmp_path / ("reads.fq.gz" if mode == "fastq_gz" else "reads.fq")
+        p.write_bytes(gzip.compress(text) if mode == "fastq_gz" else text)
         args += ["-O", str(p), "-n", "4", "-b", "7"]
     else:
         text = synth.fasta_text(names, seqs, width=60)
@@ -295,3 +306,50 @@ def test_gpu_database_build_is_byte_identical_to_cpu_build(tmp_path, variant):
     assert open(str(tmp_path / "ocpu.csv")).read() == open(str(tmp_path / "ogpu.csv")).read()
     for d in dirs.values():
         os.remove(str(d / (name + ".sz")))
+
+
+def _input_harness(tmp_path):
+    exe = str(tmp_path / "host_input")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"],
+                   check=True)
+    return exe
+
+
+def test_input_images_gzip_and_pairing(tmp_path):
+    """host/input.hpp on the CPU: gzip members are inflated in memory, mates are joined as the
+    reference's mergePairedFiles does (src/file.cc:205-268), errors keep the reference's wording"""
+    import gzip
+    exe = _input_harness(tmp_path)
+    rng = np.random.default_rng(5)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=int(n))) for n in rng.integers(30, 260, size=400)]
+    names = [b"read%d extra words" % i for i in range(len(seqs))]
+    fq = synth.fastq_text(names, seqs)
+    plain, gz, gz2, bad = (tmp_path / n for n in ("a.fq", "a.fq.gz", "a2.fq.gz", "bad.fq.gz"))
+    plain.write_bytes(fq)
+    gz.write_bytes(gzip.compress(fq))
+    cut = len(fq) // 3
+    gz2.write_bytes(gzip.compress(fq[:cut]) + gzip.compress(fq[cut:]))          # concatenated members
+    bad.write_bytes(gzip.compress(fq)[:-200])                                    # truncated
+    for f in (plain, gz, gz2):
+        r = subprocess.run([exe, "load", str(f)], capture_output=True)
+        assert r.returncode == 0 and r.stdout == fq, f
+    r = subprocess.run([exe, "load", str(bad)], capture_output=True)
+    assert r.returncode == 2 and b"gzip" in r.stderr
+    r = subprocess.run([exe, "load", str(tmp_path / "missing.fq")], capture_output=True)
+    assert r.returncode == 2 and b"Failed to open" in r.stderr
+
+    # mates: ids are cut at ' ', '/', '\t', '@' and must agree
+    ids = [b"r%d" % i for i in range(len(seqs))]
+    m1 = synth.fastq_text([i + b"/1 lane=3" for i in ids], [s[:100] for s in seqs])
+    m2 = synth.fastq_text([i + b"/2" for i in ids], [s[-80:] for s in seqs])
+    (tmp_path / "m1.fq").write_bytes(m1)
+    (tmp_path / "m2.fq.gz").write_bytes(gzip.compress(m2))
+    r = subprocess.run([exe, "pair", str(tmp_path / "m1.fq"), str(tmp_path / "m2.fq.gz")], capture_output=True)
+    want = b"".join(b">" + i + b"\n" + s[:100] + b"N" + s[-80:] + b"\n" for i, s in zip(ids, seqs))
+    assert r.returncode == 0 and r.stdout == want
+    (tmp_path / "m3.fq").write_bytes(m2.replace(b"@r7/", b"@r700/", 1))
+    r = subprocess.run([exe, "pair", str(tmp_path / "m1.fq"), str(tmp_path / "m3.fq")], capture_output=True)
+    assert r.returncode == 2 and b"read id does not match between files" in r.stderr
+    (tmp_path / "m4.fa").write_bytes(synth.fasta_text(ids, seqs))
+    r = subprocess.run([exe, "pair", str(tmp_path / "m1.fq"), str(tmp_path / "m4.fa")], capture_output=True)
+    assert r.returncode == 2 and b"different format" in r.stderr
