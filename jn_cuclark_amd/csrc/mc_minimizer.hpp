@@ -11,14 +11,18 @@
 // hits iff its canonical value is a stored k-mer, with that k-mer's label.  Only the
 // in-HBM arrangement differs, built once at load from the same arrays:
 //
-//   K(c)    = min over the k-m+1 windows w of canonical k-mer c of key64(min(w, rc(w)))
+//   K(c)    = min over the k-m+1 = 13 windows w of canonical k-mer c of key(min(w, rc(w)))
 //             (orientation-free: x and rc(x) have the same set of canonical m-mers)
 //   line(c) = mulhi(mix32(K(c)), n_lines)
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
-//             12 labels (u16), dword30 = count | extra_lines<<8, dword31 = first extra line
+//             12 labels (u16), dword30 = extra lines (16 bits) | Bloom word over their k-mers
+//             (16 bits), dword31 = first extra line
 //   extra lines (same shape) hold what does not fit; they are contiguous per line.
 //
 // Lookup is exact: the stored key is the whole canonical k-mer.
+//
+// The query kernel (mz_query_kernel below) is bound by instruction issue and by its register
+// and LDS budget, not by DRAM: see the notes at opaque(), at the launch bounds and DESIGN.md 3-4.
 #pragma once
 
 #include "mc_device.hpp"
@@ -32,21 +36,13 @@ static constexpr int MZ_MAXW = 13;            // windows per k-mer: w = k - m + 
 #ifndef MC_MZ_NS
 #define MC_MZ_NS 2
 #endif
-static constexpr int MZ_NS = MC_MZ_NS;        // 64-k-mer slots per step (a 150 bp read = one step of 2)
+static constexpr int MZ_NS = MC_MZ_NS;        // k-mer positions per lane and step (a 150 bp read = one step of 128)
 #ifndef MC_MZ_RUNS
 #define MC_MZ_RUNS (16 * MC_MZ_NS)
 #endif
 static constexpr int MZ_RUNS = MC_MZ_RUNS;    // runs (distinct lines) fetched per batch (multiple of 8)
 static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: keeps equal offsets of different
                                                 // runs on different banks (a 128-byte stride is a 9-way conflict)
-
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
-{
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return x;
-}
 
 // minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k > 12)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
