@@ -106,10 +106,11 @@ __device__ __forceinline__ uint64_t kmer_min_key(uint64_t c, uint32_t k, uint32_
     return best;
 }
 
+// The key is a hash already (mmer_key); being a window MINIMUM skews its top bits only, so the line
+// is drawn from the low word, stirred with the high one: 3 VALU ops.
 __device__ __forceinline__ uint32_t line_of(uint64_t K, uint32_t n_lines)
 {
-    uint32_t h = ((uint32_t)(K >> 32) * 0x85EBCA6Bu) ^ (uint32_t)K;
-    h ^= h >> 15; h *= 0xC2B2AE35u; h ^= h >> 16;
+    const uint32_t h = ((uint32_t)(K >> 32) * 0x9E3779B1u) ^ (uint32_t)K;
     return __umulhi(h, n_lines);
 }
 
