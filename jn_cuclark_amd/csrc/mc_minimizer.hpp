@@ -47,22 +47,31 @@ static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: 
 // minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k > 12)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
 
-// Ordering key of a canonical m-mer: one 64-bit multiply-fold, of which the top 52 bits
-// are kept as the mantissa of a double in [1, 2).  For such doubles numeric order = integer
-// order of the bit pattern, so the window minimum is ONE v_min_f64 per element instead of a
-// 64-bit compare and two selects.  The minimizer KEY of a k-mer is the smallest key over its
-// windows -- the same for x and rc(x), which contain the same canonical m-mers; two m-mers
-// that share a key (2^-52) merely share lines.  (32-bit keys are too few: the minima of
-// 6.4e9 k-mers crowd into a few 1e8 values and pile unrelated minimizers onto a line.)
-static constexpr uint64_t MZ_KEY_ONE = 0x3FF0000000000000ull;     // 1.0
+// Ordering key of a canonical m-mer (m <= 20: below 2^40): t = low word of lo*C1, stirred with the
+// high byte -- a bijection of lo for every hi, its top bits a multiplicative hash of all of lo -- then
+// 20 more bits of the product.  The 52 bits are the mantissa of a double in [1, 2): for such doubles
+// numeric order = integer order of the bit pattern, so a window minimum is ONE v_min_f64 per element
+// instead of a 64-bit compare and two selects.  6 VALU ops (v_mad_u64_u32, v_mul, v_xor, two
+// v_alignbit).  The minimizer KEY of a k-mer is the smallest key over its windows -- the same for x
+// and rc(x), which contain the same canonical m-mers; two m-mers that share a key merely share lines.
+// (32-bit keys are too few: the minima of 6.4e9 k-mers crowd into a few 1e8 values and pile unrelated
+// minimizers onto a line.)
 static constexpr uint64_t MZ_KEY_NONE = 0x4000000000000000ull;    // 2.0: above every key
+
+__device__ __forceinline__ uint64_t key_of_canonical(uint64_t cw)
+{
+    const uint32_t lo = (uint32_t)cw, hi = (uint32_t)(cw >> 32);
+    const uint64_t p = (uint64_t)lo * 0x9E3779B1u;
+    const uint32_t t = (uint32_t)p ^ (hi * 0x85EBCA6Bu);
+    const uint32_t khi = __builtin_amdgcn_alignbit(0x3FFu, t, 12);                    // 0x3FF00000 | t >> 12
+    const uint32_t klo = __builtin_amdgcn_alignbit(t, (uint32_t)(p >> 32), 12);       // t[11:0] : p[63:44]
+    return ((uint64_t)khi << 32) | klo;
+}
 
 __device__ __forceinline__ uint64_t mmer_key(uint64_t w, uint32_t m)
 {
     const uint64_t rc = revcomp(w, m);
-    uint64_t z = (w < rc ? w : rc) * 0x9E3779B97F4A7C15ull;
-    z ^= z >> 32;
-    return MZ_KEY_ONE | (z >> 12);
+    return key_of_canonical(w < rc ? w : rc);
 }
 
 __device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b)
@@ -75,9 +84,7 @@ __device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b)
 // the same from the m-mer and its reverse complement when both are at hand
 __device__ __forceinline__ uint64_t mmer_key2(uint64_t w, uint64_t rcw)
 {
-    uint64_t z = (w < rcw ? w : rcw) * 0x9E3779B97F4A7C15ull;
-    z ^= z >> 32;
-    return MZ_KEY_ONE | (z >> 12);
+    return key_of_canonical(w < rcw ? w : rcw);
 }
 
 // A copy of a per-lane value the compiler cannot trace back: what is derived from it is computed
@@ -599,28 +606,29 @@ void mz_query_kernel(const MzArgs A)
                 for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
             }
             if (a.flags & 1u) {
-                const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
-                const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
-                uint32_t k1, k2, sum;
-                if (n_acc <= 1u) {              // most reads hit no target or one: nothing to reduce
-                    k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
-                    k2 = 0u;
-                    sum = (uint32_t)__builtin_amdgcn_readlane((int)(valid ? acc_c : 0u), 0);
+                // the row [sumN, idxBest+1, best, idxSecond+1, second] as five wave-uniform values
+                uint32_t o0, o1, o2, o3 = 0u, o4 = 0u;
+                if (n_acc <= 1u) {              // most reads hit no target or one: lane 0 has it all
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)acc_t, 0);
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)acc_c, 0);
+                    const bool has = n_acc == 1u;
+                    o0 = has ? (c0 & 0xFFFFu) : 0u;
+                    o1 = has ? (t0 & 0xFFFFu) + 1u : 0u;
+                    o2 = has ? (c0 > 0xFFFFu ? 0xFFFFu : c0) : 0u;
                 } else {
-                    k1  = wave_max_u32(key);
-                    k2  = wave_max_u32(key == k1 ? 0u : key);
-                    sum = wave_sum_u32(valid ? acc_c : 0u);
+                    const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
+                    const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
+                    const uint32_t k1  = wave_max_u32(key);
+                    const uint32_t k2  = wave_max_u32(key == k1 ? 0u : key);
+                    const uint32_t sum = wave_sum_u32(valid ? acc_c : 0u);
+                    o0 = sum & 0xFFFFu;
+                    o1 = k1 ? (0xFFFFu - (k1 & 0xFFFFu)) + 1u : 0u;
+                    o2 = k1 >> 16;
+                    o3 = k2 ? (0xFFFFu - (k2 & 0xFFFFu)) + 1u : 0u;
+                    o4 = k2 >> 16;
                 }
-                uint32_t out = 0;
                 const uint32_t lo = opaque(lane);
-                switch (lo) {
-                case 0: out = sum & 0xFFFFu; break;
-                case 1: out = k1 ? (0xFFFFu - (k1 & 0xFFFFu)) + 1u : 0u; break;
-                case 2: out = k1 >> 16; break;
-                case 3: out = k2 ? (0xFFFFu - (k2 & 0xFFFFu)) + 1u : 0u; break;
-                case 4: out = k2 >> 16; break;
-                default: break;
-                }
+                const uint32_t out = lo == 0u ? o0 : lo == 1u ? o1 : lo == 2u ? o2 : lo == 3u ? o3 : o4;
                 if (lo < 5u) a.final_rows[rd * 5u + lo] = (uint16_t)out;
             }
         }
