@@ -487,10 +487,14 @@ void mz_query_kernel(const MzArgs A)
                     uint32_t lab[MZ_NS];
 #pragma unroll
                     for (int s = 0; s < MZ_NS; s++) { hit[s] = false; lab[s] = 0; }
-                    for (uint32_t rb = 0; rb < n_runs; rb += MZ_RUNS) {
+                    // one batch of up to MZ_RUNS runs; ALL = the step has no more than that (nearly always):
+                    // no per-lane range tests
+                    auto batch = [&](const uint32_t rb, auto all_c) {
+                        constexpr bool ALL = decltype(all_c)::value;
+                        auto in_batch = [&](int s) -> bool { return ALL || (run[s] >= rb && run[s] < rb + MZ_RUNS); };
 #pragma unroll
                         for (int s = 0; s < MZ_NS; s++)
-                            if (leader[s] && run[s] >= rb && run[s] < rb + MZ_RUNS) runline[run[s] - rb] = line[s];
+                            if (leader[s] && in_batch(s)) runline[run[s] - rb] = line[s];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t nb = n_runs - rb < (uint32_t)MZ_RUNS ? n_runs - rb : (uint32_t)MZ_RUNS;
@@ -515,12 +519,13 @@ void mz_query_kernel(const MzArgs A)
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int s = 0; s < MZ_NS; s++) {
-                            if (active[s] && run[s] >= rb && run[s] < rb + MZ_RUNS) {
+                            if (active[s] && in_batch(s)) {
                                 const uint8_t *L = linebuf + (run[s] - rb) * MZ_LSTRIDE;
                                 uint32_t hdr, eb;
                                 hit[s] = mz_match_line(L, c[s], lab[s], hdr, eb);
-                                const uint32_t extra = hdr & 0xFFFFu;
-                                if (!hit[s] && extra && ((hdr >> extra_bit(c[s])) & 1u)) {   // rare: lines beyond the first
+                                // rare: lines beyond the first (a Bloom bit is set only where extra lines exist)
+                                if (!hit[s] && ((hdr >> extra_bit(c[s])) & 1u)) {
+                                    const uint32_t extra = hdr & 0xFFFFu;
                                     for (uint32_t e = 0; e < extra && !hit[s]; e++) {
                                         const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
                                         u32x4 xv[MZ_CAP / 2];
@@ -539,6 +544,11 @@ void mz_query_kernel(const MzArgs A)
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+                    };
+                    if (n_runs <= (uint32_t)MZ_RUNS) {
+                        if (n_runs) batch(0u, std::true_type{});
+                    } else {
+                        for (uint32_t rb = 0; rb < n_runs; rb += MZ_RUNS) batch(rb, std::false_type{});
                     }
 
                     // fold the hits into the accumulator (as in query_kernel)
