@@ -1,4 +1,6 @@
-// VALU issue-rate probe: time N dependent-chain-free ops per wave for a few opcodes.
+// VALU issue-rate probe: time N independent ops per wave for a few opcodes (MI355X: v_mul_lo_u32,
+// v_mul_hi_u32, v_min_f64 and v_lshrrev_b64 issue at the full rate; a u64 multiply is 4 ops, a u64 min 3).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/valu_rate tools/ubench/valu_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
