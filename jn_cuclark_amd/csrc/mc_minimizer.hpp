@@ -262,9 +262,9 @@ __device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, u
 }
 
 // Occupancy is what this kernel lives on (measured on the headline workload, after the register
-// diet: 5 waves/SIMD 934, 6 waves 1022, 7 waves 1047, 8 waves with 48 B of scratch 977 Mreads/s):
-// <= 72 VGPRs and <= 5760 bytes of LDS per wave give 7 workgroups per CU (5792 bytes already
-// drop one: 776 Mreads/s).
+// diet: 5 waves/SIMD 934, 6 waves 1022, 7 waves 1047-1056, 8 waves (24 runs per batch to fit the LDS,
+// no scratch) 1032 Mreads/s): <= 72 VGPRs and <= 5760 bytes of LDS per wave give 7 workgroups per CU
+// (5792 bytes already drop one: 776 Mreads/s).
 #ifndef MC_MZ_MIN_WAVES
 #define MC_MZ_MIN_WAVES 7
 #endif
