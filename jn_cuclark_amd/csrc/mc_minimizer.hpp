@@ -200,6 +200,64 @@ __global__ void mz_header_kernel(const uint32_t *extra, const uint32_t *extra_ba
     }
 }
 
+// Lines that overflow: decide WHICH k-mers stay in the first line.  The placing pass fills slots in
+// arrival order, which splits the k-mers of one minimizer (a super-k-mer of a genome: up to 13
+// consecutive k-mers) between the first line and its extra lines, so a read crossing that region pays
+// the dependent extra-line fetch for every such run.  Here the chain is rewritten with whole groups
+// first: entries sorted by (size of their minimizer group, descending; minimizer key; k-mer).  One
+// thread per overflowing line; chains of more than MZ_REGROUP_MAX k-mers stay as placed.  The result
+// no longer depends on the order the atomics happened to run in.
+static constexpr int MZ_REGROUP_MAX = 96;
+__global__ __launch_bounds__(64)
+void mz_regroup_kernel(const uint32_t *count, const uint32_t *extra_base, uint32_t n_lines, uint32_t k, uint32_t m,
+                       uint8_t *lines, uint8_t *extra_lines)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
+        const uint32_t n = count[i];
+        if (n <= (uint32_t)MZ_CAP || n > (uint32_t)MZ_REGROUP_MAX) continue;
+        uint8_t *first = lines + i * MZ_LINE;
+        uint8_t *more = extra_lines + (uint64_t)extra_base[i] * MZ_LINE;
+        auto slot_line = [&](uint32_t e) -> uint8_t * { return e < (uint32_t)MZ_CAP ? first : more + (uint64_t)(e / MZ_CAP - 1u) * MZ_LINE; };
+        uint64_t key[MZ_REGROUP_MAX], mk[MZ_REGROUP_MAX];
+        uint16_t lab[MZ_REGROUP_MAX];
+        uint8_t  gsz[MZ_REGROUP_MAX], ord[MZ_REGROUP_MAX];
+        for (uint32_t e = 0; e < n; e++) {
+            const uint8_t *L = slot_line(e);
+            key[e] = reinterpret_cast<const uint64_t *>(L)[e % MZ_CAP];
+            lab[e] = reinterpret_cast<const uint16_t *>(L + 8 * MZ_CAP)[e % MZ_CAP];
+            mk[e] = kmer_min_key(key[e], k, m);
+        }
+        for (uint32_t e = 0; e < n; e++) {
+            uint32_t g = 0;
+            for (uint32_t f = 0; f < n; f++) g += (mk[f] == mk[e]) ? 1u : 0u;
+            gsz[e] = (uint8_t)g;
+            ord[e] = (uint8_t)e;
+        }
+        auto before = [&](uint32_t a, uint32_t b) -> bool {        // strict order of entries a, b
+            if (gsz[a] != gsz[b]) return gsz[a] > gsz[b];
+            if (mk[a] != mk[b]) return mk[a] < mk[b];
+            return key[a] < key[b];
+        };
+        for (uint32_t e = 1; e < n; e++) {                          // insertion sort of the index
+            const uint8_t v = ord[e];
+            uint32_t j = e;
+            while (j > 0 && before(v, ord[j - 1])) { ord[j] = ord[j - 1]; j--; }
+            ord[j] = v;
+        }
+        uint32_t bloom = 0;
+        for (uint32_t e = 0; e < n; e++) {
+            uint8_t *L = slot_line(e);
+            const uint32_t src = ord[e];
+            reinterpret_cast<uint64_t *>(L)[e % MZ_CAP] = key[src];
+            reinterpret_cast<uint16_t *>(L + 8 * MZ_CAP)[e % MZ_CAP] = lab[src];
+            if (e >= (uint32_t)MZ_CAP) bloom |= 1u << extra_bit(key[src]);
+        }
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
+        hdr[0] = (hdr[0] & 0xFFFFu) | bloom;                        // extra_bit() already counts from bit 16
+    }
+}
+
 // exclusive scan of u32 -> u32 (per-workgroup sums scanned on the host)
 static __global__ __launch_bounds__(RL_THREADS)
 void mz_blocksum_kernel(const uint32_t *v, uint64_t n, unsigned long long *blk)
