@@ -290,7 +290,10 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
 int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
              uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
 {
-    if (c->index_mode == 1 && c->k >= 16) {
+    // the minimizer index needs a minimizer space (canonical m-mers) well above the number of lines
+    const uint32_t mz_m = mc::mz::mmer_len(c->k);
+    const bool mz_ok = c->k >= 16 && mz_m >= 6 && (mz_m >= 20 || (1ull << (2 * mz_m - 1)) >= 4 * (n_keys / 6 + 1024));
+    if (c->index_mode == 1 && mz_ok) {
         const int rcm = relayout_mz(c, d_sz, d_keys, d_labels, n_keys, shard_begin, shard_end);
         if (rcm != MC_ENOMEM) return rcm;
         free_db(c);                      // not enough HBM for the minimizer lines: direct table

@@ -32,7 +32,15 @@ namespace mz {
 
 static constexpr int MZ_LINE = 128;
 static constexpr int MZ_CAP = 12;
-static constexpr int MZ_MAXW = 13;            // windows per k-mer: w = k - m + 1 <= 13
+#ifndef MC_MZ_MAXW
+#define MC_MZ_MAXW 11
+#endif
+// windows per k-mer: w = k - m + 1, odd (the window is read in 16-byte pairs).  Measured on the headline
+// workload (k = 31): w = 7 / 9 / 11 / 13 / 15 / 17 -> 1141 / 1229 / 1231 / 1167 / 748 / 101 Mreads/s: fewer
+// windows mean more lines per read (density 2/(w+1)) but smaller minimizer groups and a larger minimizer
+// space (4^m): past w = 13 unrelated minimizers crowd the lines.
+static constexpr int MZ_MAXW = MC_MZ_MAXW;
+static_assert(MZ_MAXW % 2 == 1 && MZ_MAXW >= 3 && MZ_MAXW <= 17, "window count");
 #ifndef MC_MZ_NS
 #define MC_MZ_NS 2
 #endif
@@ -45,7 +53,7 @@ static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: 
                                                 // runs on different banks (a 128-byte stride is a 9-way conflict)
 
 // minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k > 12)
-__host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > 12 ? k - 12 : 1; }
+__host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > (uint32_t)MZ_MAXW - 1u ? k - ((uint32_t)MZ_MAXW - 1u) : 1u; }
 
 // Ordering key of a canonical m-mer (m <= 20: below 2^40): t = low word of lo*C1, stirred with the
 // high byte -- a bijection of lo for every hi, its top bits a multiplicative hash of all of lo -- then
