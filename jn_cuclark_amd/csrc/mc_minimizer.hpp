@@ -5,13 +5,13 @@
 // (~50 G requests/s).  Consecutive k-mers of a read overlap in k-1 bases;
 // k-mers that share their minimizer (the smallest, under a fixed hash, of the canonical
 // m-mers inside the k-mer) can share a bucket.  A 150 bp read has 120 k-mers but only
-// ~2*120/(k-m+2) distinct minimizers, so it needs ~17 line fetches instead of 120.
+// ~2*120/(k-m+2) distinct minimizers, so it needs ~21 line fetches instead of 120.
 //
 // What stays the same.  The on-disk database, the batch format, and the answer: a k-mer
 // hits iff its canonical value is a stored k-mer, with that k-mer's label.  Only the
 // in-HBM arrangement differs, built once at load from the same arrays:
 //
-//   K(c)    = min over the k-m+1 = 13 windows w of canonical k-mer c of key(min(w, rc(w)))
+//   K(c)    = min over the k-m+1 = MZ_MAXW (11) windows w of canonical k-mer c of key(min(w, rc(w)))
 //             (orientation-free: x and rc(x) have the same set of canonical m-mers)
 //   line(c) = mulhi(mix32(K(c)), n_lines)
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
@@ -55,7 +55,7 @@ static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: 
 // minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k > 12)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > (uint32_t)MZ_MAXW - 1u ? k - ((uint32_t)MZ_MAXW - 1u) : 1u; }
 
-// Ordering key of a canonical m-mer (m <= 20: below 2^40): t = low word of lo*C1, stirred with the
+// Ordering key of a canonical m-mer (m <= 22: below 2^44; any value works, the high word is just stirred in): t = low word of lo*C1, stirred with the
 // high byte -- a bijection of lo for every hi, its top bits a multiplicative hash of all of lo -- then
 // 20 more bits of the product.  The 52 bits are the mantissa of a double in [1, 2): for such doubles
 // numeric order = integer order of the bit pattern, so a window minimum is ONE v_min_f64 per element
@@ -365,7 +365,7 @@ void mz_query_kernel(const MzArgs A)
     uint64_t *keyv = reinterpret_cast<uint64_t *>(linebuf);     // aliases the parked lines (see above)
 
     const uint32_t k = a.k, m = A.m;
-    constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - 12 (mmer_len), k >= 16
+    constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - (MZ_MAXW - 1) (mmer_len)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
     const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
