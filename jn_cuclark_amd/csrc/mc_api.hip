@@ -208,8 +208,8 @@ int mz_build_passes(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
                        n_lines, d_count, d_cursor, d_ebase, c->d_mz_lines, c->d_mz_extra);
     HIPCHK(hipGetLastError());
     if (*n_extra && !getenv("MC_MZ_NO_REGROUP")) {      // whole minimizer groups first in overflowing lines
-        const int gr = (int)std::min<uint64_t>(((uint64_t)n_lines + 63) / 64, (uint64_t)c->n_cu * 64);
-        hipLaunchKernelGGL(mc::mz::mz_regroup_kernel, dim3(gr), dim3(64), 0, st, d_count, d_ebase, n_lines, c->k,
+        const int gr = (int)std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, (uint64_t)c->n_cu * 16);
+        hipLaunchKernelGGL(mc::mz::mz_regroup_kernel, dim3(gr), dim3(256), 0, st, d_count, d_ebase, n_lines, c->k,
                            c->mz_m, c->d_mz_lines, c->d_mz_extra);
         HIPCHK(hipGetLastError());
     }

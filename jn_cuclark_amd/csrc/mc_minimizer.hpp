@@ -211,60 +211,66 @@ __global__ void mz_header_kernel(const uint32_t *extra, const uint32_t *extra_ba
 }
 
 // Lines that overflow: decide WHICH k-mers stay in the first line.  The placing pass fills slots in
-// arrival order, which splits the k-mers of one minimizer (a super-k-mer of a genome: up to 13
+// arrival order, which splits the k-mers of one minimizer (a super-k-mer of a genome: up to 11
 // consecutive k-mers) between the first line and its extra lines, so a read crossing that region pays
 // the dependent extra-line fetch for every such run.  Here the chain is rewritten with whole groups
 // first: entries sorted by (size of their minimizer group, descending; minimizer key; k-mer).  One
-// thread per overflowing line; chains of more than MZ_REGROUP_MAX k-mers stay as placed.  The result
-// no longer depends on the order the atomics happened to run in.
-static constexpr int MZ_REGROUP_MAX = 96;
-__global__ __launch_bounds__(64)
+// WAVE per overflowing line, one lane per k-mer (chains of more than 64 k-mers stay as placed): group
+// size and rank are counted against every other entry by broadcast, so nothing is sorted in memory.
+// The result no longer depends on the order the atomics happened to run in.
+static constexpr int MZ_REGROUP_MAX = 64;
+__global__ __launch_bounds__(256)
 void mz_regroup_kernel(const uint32_t *count, const uint32_t *extra_base, uint32_t n_lines, uint32_t k, uint32_t m,
                        uint8_t *lines, uint8_t *extra_lines)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
-        const uint32_t n = count[i];
-        if (n <= (uint32_t)MZ_CAP || n > (uint32_t)MZ_REGROUP_MAX) continue;
-        uint8_t *first = lines + i * MZ_LINE;
-        uint8_t *more = extra_lines + (uint64_t)extra_base[i] * MZ_LINE;
-        auto slot_line = [&](uint32_t e) -> uint8_t * { return e < (uint32_t)MZ_CAP ? first : more + (uint64_t)(e / MZ_CAP - 1u) * MZ_LINE; };
-        uint64_t key[MZ_REGROUP_MAX], mk[MZ_REGROUP_MAX];
-        uint16_t lab[MZ_REGROUP_MAX];
-        uint8_t  gsz[MZ_REGROUP_MAX], ord[MZ_REGROUP_MAX];
-        for (uint32_t e = 0; e < n; e++) {
-            const uint8_t *L = slot_line(e);
-            key[e] = reinterpret_cast<const uint64_t *>(L)[e % MZ_CAP];
-            lab[e] = reinterpret_cast<const uint16_t *>(L + 8 * MZ_CAP)[e % MZ_CAP];
-            mk[e] = kmer_min_key(key[e], k, m);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * 64u; base < n_lines; base += n_waves * 64u) {
+        const uint64_t mine = base + lane;
+        const uint32_t n_mine = mine < n_lines ? count[mine] : 0u;
+        uint64_t todo = __ballot(n_mine > (uint32_t)MZ_CAP && n_mine <= (uint32_t)MZ_REGROUP_MAX);
+        while (todo) {
+            const uint32_t l = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+            todo &= todo - 1u;
+            const uint64_t i = base + l;
+            const uint32_t n = lane_bcast(n_mine, l);
+            uint8_t *first = lines + i * MZ_LINE;
+            uint8_t *more = extra_lines + (uint64_t)extra_base[i] * MZ_LINE;
+            auto slot_line = [&](uint32_t e) -> uint8_t * { return e < (uint32_t)MZ_CAP ? first : more + (uint64_t)(e / MZ_CAP - 1u) * MZ_LINE; };
+            const bool have = lane < n;
+            uint64_t key = ~0ull, mk = ~0ull;
+            uint32_t lab = 0;
+            if (have) {
+                const uint8_t *L = slot_line(lane);
+                key = reinterpret_cast<const uint64_t *>(L)[lane % MZ_CAP];
+                lab = reinterpret_cast<const uint16_t *>(L + 8 * MZ_CAP)[lane % MZ_CAP];
+                mk = kmer_min_key(key, k, m);
+            }
+            uint32_t gsz = 0;
+            for (uint32_t f = 0; f < n; f++) gsz += (lane_bcast64(mk, f) == mk) ? 1u : 0u;
+            uint32_t rank = 0;                       // entries that come before this one (keys are distinct)
+            for (uint32_t f = 0; f < n; f++) {
+                const uint32_t gf = lane_bcast(gsz, f);
+                const uint64_t mf = lane_bcast64(mk, f), kf = lane_bcast64(key, f);
+                const bool before = gf != gsz ? gf > gsz : (mf != mk ? mf < mk : kf < key);
+                rank += before ? 1u : 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // every entry is in registers before any is rewritten
+            __builtin_amdgcn_wave_barrier();
+            uint32_t bloom = 0;
+            if (have) {
+                uint8_t *L = slot_line(rank);
+                reinterpret_cast<uint64_t *>(L)[rank % MZ_CAP] = key;
+                reinterpret_cast<uint16_t *>(L + 8 * MZ_CAP)[rank % MZ_CAP] = (uint16_t)lab;
+                if (rank >= (uint32_t)MZ_CAP) bloom = extra_mask(key);
+            }
+            for (int o = 32; o > 0; o >>= 1) bloom |= (uint32_t)__shfl_xor((int)bloom, o, 64);
+            if (lane == 0) {
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
+                hdr[0] = (hdr[0] & 0xFFFFu) | bloom;            // extra_mask() sits in the high half
+            }
         }
-        for (uint32_t e = 0; e < n; e++) {
-            uint32_t g = 0;
-            for (uint32_t f = 0; f < n; f++) g += (mk[f] == mk[e]) ? 1u : 0u;
-            gsz[e] = (uint8_t)g;
-            ord[e] = (uint8_t)e;
-        }
-        auto before = [&](uint32_t a, uint32_t b) -> bool {        // strict order of entries a, b
-            if (gsz[a] != gsz[b]) return gsz[a] > gsz[b];
-            if (mk[a] != mk[b]) return mk[a] < mk[b];
-            return key[a] < key[b];
-        };
-        for (uint32_t e = 1; e < n; e++) {                          // insertion sort of the index
-            const uint8_t v = ord[e];
-            uint32_t j = e;
-            while (j > 0 && before(v, ord[j - 1])) { ord[j] = ord[j - 1]; j--; }
-            ord[j] = v;
-        }
-        uint32_t bloom = 0;
-        for (uint32_t e = 0; e < n; e++) {
-            uint8_t *L = slot_line(e);
-            const uint32_t src = ord[e];
-            reinterpret_cast<uint64_t *>(L)[e % MZ_CAP] = key[src];
-            reinterpret_cast<uint16_t *>(L + 8 * MZ_CAP)[e % MZ_CAP] = lab[src];
-            if (e >= (uint32_t)MZ_CAP) bloom |= extra_mask(key[src]);
-        }
-        uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
-        hdr[0] = (hdr[0] & 0xFFFFu) | bloom;                        // extra_mask() sits in the high half
     }
 }
 
