@@ -263,20 +263,31 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
 
+    # the ONE JSON line goes out before anything that is not part of the measurement can stall
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+    watchdog = None
+    if world > 1:
+        # nothing below may keep the job alive: a rank stuck in a collective (a peer died) ends cleanly
+        import threading
+        watchdog = threading.Timer(300.0, lambda: (log("bench: post-measurement phase timed out"), os._exit(0)))
+        watchdog.daemon = True
+        watchdog.start()
     if world > 1 and not shard_mode and not args.no_shard_check:
         del d_sz, d_keys, d_labels
         db.close()
         torch.cuda.empty_cache()
         chk = shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend)
         if rank == 0:
-            out["shard_path"] = chk
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+            print("shard_path " + json.dumps(chk), file=sys.stderr, flush=True)
 
     db.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend):
