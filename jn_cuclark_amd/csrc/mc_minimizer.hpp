@@ -572,22 +572,26 @@ void mz_query_kernel(const MzArgs A)
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t nb = n_runs - rb < (uint32_t)MZ_RUNS ? n_runs - rb : (uint32_t)MZ_RUNS;
-                        // 8 lanes fetch one 128-byte line; MZ_RUNS/8 rounds, all issued before use
+                        // 8 lanes fetch one 128-byte line; MZ_RUNS/8 rounds, all issued before use.
+                        // Rounds are skipped as a whole (scalar branch); inside a round the lane groups
+                        // past the last run re-read that run's line (same request, no predication).
                         u32x4 v[MZ_RUNS / 8];
                         const uint32_t lf = opaque(lane);
 #pragma unroll
                         for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
-                            const uint32_t j = 8u * rd + (lf >> 3);
-                            v[rd] = u32x4{~0u, ~0u, ~0u, ~0u};
-                            if (j < nb) {
-                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)runline[j] * MZ_LINE) + (lf & 7u);
+                            if (8u * rd < nb) {
+                                const uint32_t j = 8u * rd + (lf >> 3);
+                                const uint32_t jc = j < nb ? j : nb - 1u;
+                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)runline[jc] * MZ_LINE) + (lf & 7u);
                                 v[rd] = __builtin_nontemporal_load(src);
                             }
                         }
 #pragma unroll
                         for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
-                            const uint32_t j = 8u * rd + (lf >> 3);
-                            if (j < nb) *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lf & 7u) * 16u) = v[rd];
+                            if (8u * rd < nb) {
+                                const uint32_t j = 8u * rd + (lf >> 3);
+                                *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lf & 7u) * 16u) = v[rd];
+                            }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
