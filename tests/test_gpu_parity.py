@@ -354,3 +354,39 @@ def test_minimizer_extra_line_chains(gpu, oracle, monkeypatch, fill, index_mode)
     assert info["n_overflow_buckets"] > 0          # extra lines exist
     assert np.array_equal(rows, want_rows)
     assert np.array_equal(got, oracle.result_rows(want_rows))
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404])
+def test_random_ragged_batches(gpu, oracle, seed):
+    """fuzz: reads of random lengths (k-3 .. 700) cut from the genomes or random, with random runs of N and
+    other non-ACGT bytes at random places -- every boundary between parts, steps (128 positions) and
+    staged pieces moves around; rows and results must equal the oracle's on both indexes"""
+    rng = np.random.default_rng(seed)
+    genomes, sz, ky, lb = small_db(glen=7000, n_targets=6)
+    names, seqs = [], []
+    for i in range(1200):
+        L = int(rng.choice([K - 3, K, K + 1, 60, 100, 127 + K, 128 + K, 129 + K, 150, 251, 400, 700]))
+        if rng.random() < 0.6:
+            g = int(rng.integers(0, len(genomes)))
+            p = int(rng.integers(0, genomes[g].size - L))
+            codes = genomes[g][p:p + L].copy()
+            mut = rng.random(L) < 0.02
+            codes[mut] = (codes[mut] + rng.integers(1, 4, size=int(mut.sum()))) & 3
+        else:
+            codes = rng.integers(0, 4, size=L).astype(np.uint8)
+        s = bytearray(synth.codes_to_ascii(codes))
+        for _ in range(int(rng.integers(0, 4))):               # runs of N / IUPAC / '-' of length 1..5
+            at = int(rng.integers(0, L))
+            for t in range(at, min(L, at + int(rng.integers(1, 6)))):
+                s[t] = rng.choice(list(b"NRY-nx"))
+        names.append(b"f%d" % i)
+        seqs.append(bytes(s))
+    text = synth.fasta_text(names, seqs, width=int(rng.choice([60, 80, 1000])))
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    odb = oracle.OracleDB.from_arrays(HT, sz, ky, lb)
+    want_rows, _ = odb.query_rows(K, rp, con, 15)
+    with _open(gpu, sz, ky, lb) as db:
+        got, rows = db.classify(rp, con, extended=True)
+    assert np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
+    assert (got[:, 2] > 0).sum() > 400
