@@ -134,9 +134,11 @@ static constexpr int STAGE_CON       = MC_STAGE_CON;   // u16 containers per wav
 // with v_bfrev_b32 instead of five swap rounds.
 __device__ __forceinline__ uint64_t revcomp(uint64_t x, uint32_t k)
 {
-    uint64_t r = __brevll(~x);
-    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
-    return r >> (64u - 2u * k);
+    // bit reversal turns each 2-bit code around as well: swap the bits of every pair back (v_bfi per half)
+    const uint32_t lo = __brev((uint32_t)(~x >> 32)), hi = __brev((uint32_t)~x);     // halves trade places
+    const uint32_t slo = ((lo >> 1) & 0x55555555u) | ((lo << 1) & 0xAAAAAAAAu);
+    const uint32_t shi = ((hi >> 1) & 0x55555555u) | ((hi << 1) & 0xAAAAAAAAu);
+    return (((uint64_t)shi << 32) | slo) >> (64u - 2u * k);
 }
 
 // Wave-wide reductions on DPP (no LDS crossbar round trips): xor butterflies inside each

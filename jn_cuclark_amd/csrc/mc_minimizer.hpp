@@ -496,8 +496,9 @@ void mz_query_kernel(const MzArgs A)
                         rc1 = (rc0 >> 2) | ((uint64_t)(3u - ((uint32_t)x1 & 3u)) << (2u * k - 2u));
                         key0 = mmer_key2(x0 >> (2u * (k - m)), rc0 & mmask);        // first m bases, both strands
                         c[0] = x0 < rc0 ? x0 : rc0;
-                        const uint64_t k1 = mmer_key2(x1 >> (2u * (k - m)), rc1 & mmask);
-                        key1 = active[1] ? k1 : MZ_KEY_NONE;
+                        // also right for the lane whose second position is nk (no k-mer there): the m-mer at nk
+                        // lies inside the part, and the tail writer below stores the same key again
+                        key1 = mmer_key2(x1 >> (2u * (k - m)), rc1 & mmask);
                         c[1] = x1 < rc1 ? x1 : rc1;
                         if constexpr (SHARDED) {
 #pragma unroll
