@@ -18,6 +18,7 @@
 #include "dbbuild.hpp"
 #include "reads.hpp"
 #include "input.hpp"
+#include "format.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -276,11 +277,26 @@ struct Classifier {
                         out += cells;
                         s_max[sl] = std::max<long>(s_max[sl], row[0]); s_min[sl] = std::min<long>(s_min[sl], row[0]); s_sum[sl] += row[0];
                     }
-                    const int m = std::snprintf(line, sizeof line, ",%g,", gamma);
-                    out.append(line, (size_t)m);
+                    // ",%g," gamma, assignment, ",%u,%g\n" best, confidence -- the two ratios without printf
+                    // where format.hpp covers them (it declines the odd cases: reads shorter than k, ties)
+                    char *o = line;
+                    *o++ = ',';
+                    const int64_t den = (int64_t)norm - (int64_t)opt.k + 1;
+                    int m = den > 0 ? fmt_ratio_g(o, total, (uint64_t)den) : 0;
+                    if (!m) m = std::snprintf(o, 64, "%g", gamma);
+                    o += m;
+                    *o++ = ',';
+                    out.append(line, (size_t)(o - line));
                     out += assign;
-                    const int m2 = std::snprintf(line, sizeof line, ",%u,%g\n", best, delta);
-                    out.append(line, (size_t)m2);
+                    o = line;
+                    *o++ = ',';
+                    o += fmt_u32(o, best);
+                    *o++ = ',';
+                    m = fmt_ratio_g(o, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
+                    if (!m) m = std::snprintf(o, 64, "%g", delta);
+                    o += m;
+                    *o++ = '\n';
+                    out.append(line, (size_t)(o - line));
                 }
             }
             for (int sl = 0; sl < nfmt; sl++) {

@@ -353,3 +353,13 @@ def test_input_images_gzip_and_pairing(tmp_path):
     (tmp_path / "m4.fa").write_bytes(synth.fasta_text(ids, seqs))
     r = subprocess.run([exe, "pair", str(tmp_path / "m1.fq"), str(tmp_path / "m4.fa")], capture_output=True)
     assert r.returncode == 2 and b"different format" in r.stderr
+
+
+def test_fast_g_format_matches_printf(tmp_path):
+    """host/format.hpp: the CSV writer's printf-free "%g" of a ratio agrees with snprintf for every
+    a <= b <= 2000 and a million random pairs up to 2^20, and declines what it does not cover"""
+    exe = str(tmp_path / "host_format")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "host_format.cc")], check=True)
+    r = subprocess.run([exe, "2000", "1000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("checked ")
