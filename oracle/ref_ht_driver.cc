@@ -14,6 +14,11 @@
 //        EHashtable::Read (mmap path) and answers with EHashtable::queryElement(uint64)
 //        = hTable::find(uint64, ILBL&) (hashTable_hh.hh:358-396), the CPU function the
 //        GPU lookup mirrors.  Prints "<kmer>\t<found 0/1>\t<label>".
+//   ref_ht time <k> <base> <n> <hit_every>
+//        Single-thread timing of hTable::find: n pseudo-random forward k-mers (splitmix64 of 1..n,
+//        masked to 2k bits); every <hit_every>-th one is replaced by a k-mer read back from the table
+//        (a sure hit).  Prints "lookups <n> found <f> ns_per_lookup <t>".  oracle/time_lookup.c does
+//        the same with the restatement: the cpu_baseline "port" is not slower than the original.
 //   ref_ht kmer <k> <in.txt>
 //        in.txt: one k-base string per line.  Prints "<string>\t<vectorToIndex>\t<getReverseComplement>".
 //
@@ -29,6 +34,7 @@
 #include <algorithm>
 #include <iostream>
 #include <stdint.h>
+#include <time.h>
 
 #include "HashTableStorage_hh.hh"
 
@@ -81,6 +87,42 @@ static int cmd_query(int k, const char *base, const char *in)
     return 0;
 }
 
+static inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// the same k-mer stream as oracle/time_lookup.c: stored k-mers come from base.hits (u64 values, binary)
+static int cmd_time(int k, const char *base, size_t n, size_t hit_every)
+{
+    EHashtable<REF_KEY_T, rElement> ht(k);
+    size_t fileSize = 0;
+    if (!ht.Read(base, fileSize, 1, 1, true)) { fprintf(stderr, "Read failed\n"); return 2; }
+    std::vector<uint64_t> hits;
+    {
+        std::string hf = std::string(base) + ".hits";
+        FILE *f = fopen(hf.c_str(), "rb");
+        if (f) { uint64_t v; while (fread(&v, 8, 1, f) == 1) hits.push_back(v); fclose(f); }
+    }
+    const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    std::vector<uint64_t> q(n);
+    for (size_t i = 0; i < n; i++) {
+        q[i] = splitmix64(i + 1) & mask;
+        if (hit_every && !hits.empty() && i % hit_every == 0) q[i] = hits[(i / hit_every) % hits.size()];
+    }
+    struct timespec t0, t1;
+    size_t found = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t i = 0; i < n; i++) { ILBL lab = 0; found += ht.queryElement(q[i], lab) ? 1 : 0; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double ns = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / (double)n;
+    printf("lookups %zu found %zu ns_per_lookup %.1f\n", n, found, ns);
+    return 0;
+}
+
 static int cmd_kmer(int k, const char *in)
 {
     FILE *f = fopen(in, "r");
@@ -105,9 +147,11 @@ int main(int argc, char **argv)
         return cmd_build(atoi(argv[2]), (size_t)atol(argv[3]), argv[4], argv[5]);
     if (argc >= 5 && !strcmp(argv[1], "query"))
         return cmd_query(atoi(argv[2]), argv[3], argv[4]);
+    if (argc >= 6 && !strcmp(argv[1], "time"))
+        return cmd_time(atoi(argv[2]), argv[3], (size_t)atol(argv[4]), (size_t)atol(argv[5]));
     if (argc >= 4 && !strcmp(argv[1], "kmer"))
         return cmd_kmer(atoi(argv[2]), argv[3]);
     if (argc >= 2 && !strcmp(argv[1], "htsize")) { printf("%zu\n", (size_t)HTSIZE); return 0; }
-    fprintf(stderr, "usage: %s build|query|kmer|htsize ...\n", argv[0]);
+    fprintf(stderr, "usage: %s build|query|time|kmer|htsize ...\n", argv[0]);
     return 1;
 }
