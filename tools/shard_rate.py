@@ -1,0 +1,40 @@
+"""Rate of the SHARDED query kernel on one GPU: the headline table cut into N bucket ranges, one of them
+loaded, every read of the batch looked up against it (sparse rows out), as each rank of an N-GPU sharded
+run does.  python tools/shard_rate.py [N ...]   (run on the GPU box)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from jn_cuclark_amd import CuClarkDB, synth_gpu
+from jn_cuclark_amd.dist import shard_range
+
+K, HT, T, LAM, GLEN, MAXHITS = 31, 1610612741, 4096, 3.75, 100_000, 15
+dev = torch.device("cuda", 0)
+genomes = synth_gpu.make_genomes(T, GLEN, seed=31, device=dev)
+n_reads = 10_000_000
+rp, con = synth_gpu.make_reads(genomes, n_reads, 150, seed=32)
+rows = torch.zeros((n_reads, 2 * MAXHITS + 2), dtype=torch.int16, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+for n in [int(a) for a in sys.argv[1:]] or [2, 8]:
+    shard = shard_range(HT, 0, n)
+    d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, K, HT, T, LAM, genomes=genomes, shard=shard)
+    db = CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=MAXHITS)
+    db.read_device(d_sz, d_keys, d_labels, shard=shard)
+    del d_sz, d_keys, d_labels
+    for _ in range(2):
+        db.query_device(rp, con, None, rows, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        db.query_device(rp, con, None, rows, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("shard 1/%d of the table (%.1f GB index): %.2f ms per 10 M reads = %.0f Mreads/s per GPU, rows out"
+          % (n, db.db_info()["device_bytes"] / 1e9, ms, n_reads / ms / 1e3), flush=True)
+    db.close()
+    torch.cuda.empty_cache()
