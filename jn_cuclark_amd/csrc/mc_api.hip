@@ -464,6 +464,10 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     if (c->d_mz_lines) {
         mc::mz::MzArgs m{};
         m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra; m.n_lines = c->mz_n_lines; m.m = c->mz_m;
+        // canonical k-mers are below 4^k: the floating-point remainder needs k-mer / HTSIZE < 2^32
+        const bool fp_ok = c->htsize > 1024 && c->htsize < (1ull << 32) &&
+                           (c->k < 32 ? ((unsigned __int128)1 << (2 * c->k)) <= ((unsigned __int128)c->htsize << 32) : false);
+        m.inv_htsize = fp_ok ? 1.0 / (double)c->htsize : 0.0;
         if (c->info.shard_begin != 0 || c->info.shard_end != c->htsize)
             hipLaunchKernelGGL(mc::mz::mz_query_kernel<true>, g, b, 0, st, m);
         else

@@ -50,6 +50,19 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t n, const DivU64 &dv)
     return q >> dv.shift;
 }
 
+// n mod d for the shard filter when n / d < 2^32 and d > 1024 (DivU64::add == 2, set by make_div_for):
+// the quotient is estimated in double precision -- n loses at most 9 low bits in the conversion and the
+// two roundings add 3 * 2^-53 relative, so the estimate is within one of the true quotient -- and the
+// remainder is put right by at most one +-d.  About half the vector instructions of the 64-bit magic.
+__device__ __forceinline__ uint64_t rem_u64_fp(uint64_t n, uint32_t d, double inv_d)
+{
+    const uint32_t q = (uint32_t)((double)n * inv_d);
+    int64_t r = (int64_t)(n - (uint64_t)q * d);
+    if (r < 0) r += d;
+    else if (r >= (int64_t)d) r -= d;
+    return (uint64_t)r;
+}
+
 // host side: libdivide-style magic for unsigned 64-bit division by a run-time constant
 inline DivU64 make_div(uint64_t d)
 {

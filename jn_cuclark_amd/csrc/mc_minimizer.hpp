@@ -309,6 +309,7 @@ struct MzArgs {
     const uint8_t *extra;      // extra lines
     uint32_t n_lines;
     uint32_t m;
+    double inv_htsize;         // 1/HTSIZE when the shard filter may use rem_u64_fp, else 0
 };
 
 // One lane against one 128-byte line parked in LDS.  All key loads are issued before the
@@ -474,6 +475,7 @@ void mz_query_kernel(const MzArgs A)
                     const uint32_t p0 = base + 2u * lane;
                     active[0] = p0 < nk;
                     active[1] = p0 + 1u < nk;
+                    const bool inpart[MZ_NS] = {active[0], active[1]};
                     uint64_t x0 = 0, x1 = 0, rc0 = 0, rc1 = 0;
                     uint64_t key0 = MZ_KEY_NONE, key1 = MZ_KEY_NONE;
                     c[0] = 0; c[1] = 0;
@@ -501,10 +503,17 @@ void mz_query_kernel(const MzArgs A)
                         key1 = mmer_key2(x1 >> (2u * (k - m)), rc1 & mmask);
                         c[1] = x1 < rc1 ? x1 : rc1;
                         if constexpr (SHARDED) {
+                            // runs are formed over ALL k-mers of the part (inpart); only the k-mers of this
+                            // shard are looked up (active), and only runs with such a k-mer are fetched
 #pragma unroll
                             for (int s = 0; s < MZ_NS; s++) {
-                                const uint64_t q = div_u64(c[s], a.div);
-                                const uint64_t r = c[s] - q * a.div.d;
+                                uint64_t r;
+                                if (A.inv_htsize != 0.0) {              // 4^k <= HTSIZE * 2^32: every real table
+                                    r = rem_u64_fp(c[s], (uint32_t)a.div.d, A.inv_htsize);
+                                } else {
+                                    const uint64_t q = div_u64(c[s], a.div);
+                                    r = c[s] - q * a.div.d;
+                                }
                                 active[s] = active[s] && (r >= a.shard_begin) && (r < a.shard_end);
                             }
                         }
@@ -543,12 +552,12 @@ void mz_query_kernel(const MzArgs A)
 #pragma unroll
                         for (int i = 2; i < MZ_MAXW; i++) mid = key_min(mid, v[i]);
                         const uint64_t K0 = key_min(v[0], mid), K1 = key_min(mid, v[MZ_MAXW]);
-                        line[0] = active[0] ? line_of(K0, A.n_lines) : 0xFFFFFFFFu;
-                        line[1] = active[1] ? line_of(K1, A.n_lines) : 0xFFFFFFFFu;
+                        line[0] = inpart[0] ? line_of(K0, A.n_lines) : 0xFFFFFFFFu;
+                        line[1] = inpart[1] ? line_of(K1, A.n_lines) : 0xFFFFFFFFu;
                         // second line of the lane before (DPP wave_shr:1); nothing before lane 0
                         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)line[1], 0x138, 0xf, 0xf, false);
-                        leader[0] = active[0] && line[0] != prev;
-                        leader[1] = active[1] && line[1] != line[0];
+                        leader[0] = inpart[0] && line[0] != prev;
+                        leader[1] = inpart[1] && line[1] != line[0];
                         const uint64_t b0 = __ballot(leader[0]), b1 = __ballot(leader[1]);
                         // leaders in lower lanes (v_mbcnt) = index of this lane's first run
                         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
@@ -567,9 +576,17 @@ void mz_query_kernel(const MzArgs A)
                     auto batch = [&](const uint32_t rb, auto all_c) {
                         constexpr bool ALL = decltype(all_c)::value;
                         auto in_batch = [&](int s) -> bool { return ALL || (run[s] >= rb && run[s] < rb + MZ_RUNS); };
+                        if constexpr (SHARDED) {
+                            // any k-mer of this shard publishes its run's line; runs without one keep ~0
+                            if (lane < (uint32_t)MZ_RUNS) runline[lane] = 0xFFFFFFFFu;
 #pragma unroll
-                        for (int s = 0; s < MZ_NS; s++)
-                            if (leader[s] && in_batch(s)) runline[run[s] - rb] = line[s];
+                            for (int s = 0; s < MZ_NS; s++)
+                                if (active[s] && in_batch(s)) runline[run[s] - rb] = line[s];
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < MZ_NS; s++)
+                                if (leader[s] && in_batch(s)) runline[run[s] - rb] = line[s];
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t nb = n_runs - rb < (uint32_t)MZ_RUNS ? n_runs - rb : (uint32_t)MZ_RUNS;
@@ -583,8 +600,14 @@ void mz_query_kernel(const MzArgs A)
                             if (8u * rd < nb) {
                                 const uint32_t j = 8u * rd + (lf >> 3);
                                 const uint32_t jc = j < nb ? j : nb - 1u;
-                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)runline[jc] * MZ_LINE) + (lf & 7u);
-                                v[rd] = __builtin_nontemporal_load(src);
+                                const uint32_t rl = runline[jc];
+                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)rl * MZ_LINE) + (lf & 7u);
+                                if constexpr (SHARDED) {
+                                    v[rd] = u32x4{0u, 0u, 0u, 0u};
+                                    if (rl != 0xFFFFFFFFu) v[rd] = __builtin_nontemporal_load(src);
+                                } else {
+                                    v[rd] = __builtin_nontemporal_load(src);
+                                }
                             }
                         }
 #pragma unroll
