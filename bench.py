@@ -268,10 +268,12 @@ def main():
         print(json.dumps(out), flush=True)
 
     watchdog = None
+    shard_failed = False
     if world > 1:
-        # nothing below may keep the job alive: a rank stuck in a collective (a peer died) ends cleanly
+        # nothing below may keep the job alive: a rank stuck in a collective (a peer died) ends the job --
+        # with a NON-ZERO status (the JSON line is already out and flushed)
         import threading
-        watchdog = threading.Timer(300.0, lambda: (log("bench: post-measurement phase timed out"), os._exit(0)))
+        watchdog = threading.Timer(300.0, lambda: (log("bench: post-measurement phase timed out"), os._exit(3)))
         watchdog.daemon = True
         watchdog.start()
     if world > 1 and not shard_mode and not args.no_shard_check:
@@ -281,6 +283,7 @@ def main():
         chk = shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend)
         if rank == 0:
             print("shard_path " + json.dumps(chk), file=sys.stderr, flush=True)
+        shard_failed = bool(chk.get("error")) or not chk.get("verified_equal_to_unsharded", False)
 
     db.close()
     if world > 1:
@@ -288,6 +291,8 @@ def main():
         dist.destroy_process_group()
     if watchdog is not None:
         watchdog.cancel()
+    if shard_failed:
+        raise SystemExit("bench: the sharded RCCL path failed its check (see shard_path on stderr)")
 
 
 def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend):

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t div_u64(uint64_t n, const DivU64 &dv)
     return q >> dv.shift;
 }
 
-// n mod d for the shard filter when n / d < 2^32 and d > 1024 (DivU64::add == 2, set by make_div_for):
+// n mod d for the shard filter when n / d < 2^32 and d > 1024 (MzArgs::inv_htsize != 0, set in launch_query):
 // the quotient is estimated in double precision -- n loses at most 9 low bits in the conversion and the
 // two roundings add 3 * 2^-53 relative, so the estimate is within one of the true quotient -- and the
 // remainder is put right by at most one +-d.  About half the vector instructions of the 64-bit magic.
@@ -141,6 +141,13 @@ static constexpr int GROUP_READS     = 16;     // reads staged per wave at a tim
 #define MC_STAGE_CON 1024
 #endif
 static constexpr int STAGE_CON       = MC_STAGE_CON;   // u16 containers per wave LDS slice
+
+// Per-target hit counts are u16 on the wire (reference RESULTS, dataType.hh:37-43).  The reference's
+// packed 2 x u16 shared-memory atomics carry into the neighbouring target at 65 536 (CuClarkDB.cu:1104-1108):
+// no defined behaviour to reproduce.  ONE rule here, in every output (sparse rows, merged rows, fused
+// and unfused final rows): a count saturates at 65 535.  Saturating addition of non-negative numbers is
+// associative, so the rule is shard-invariant; sumN stays the u16 sum of those counts (it wraps, :1370-1372).
+__host__ __device__ __forceinline__ uint32_t sat_u16(uint32_t c) { return c > 0xFFFFu ? 0xFFFFu : c; }
 
 // reverse complement: complement every 2-bit code, reverse the order of the codes,
 // keep the low 2k bits.  Same function as reference CuClarkDB.cu:1196-1203, written
@@ -510,23 +517,23 @@ void query_kernel(const QueryArgs a)
                 if (lane == 0) row[0] = (uint16_t)n_keep;
                 if (valid) {
                     row[1 + 2 * rank] = (uint16_t)acc_t;
-                    row[2 + 2 * rank] = (uint16_t)acc_c;
+                    row[2 + 2 * rank] = (uint16_t)sat_u16(acc_c);
                 }
                 for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
             }
             if (a.flags & 1u) {                                   // fused top-2 (ref :1361-1411)
                 // ascending-id scan with strict '>' == max count, ties to the smaller id
-                const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
+                const uint32_t cc  = sat_u16(acc_c);
                 const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
                 uint32_t k1, k2, sum;
                 if (n_acc <= 1u) {              // most reads hit no target or one: nothing to reduce
                     k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
                     k2 = 0u;
-                    sum = (uint32_t)__builtin_amdgcn_readlane((int)(valid ? acc_c : 0u), 0);
+                    sum = (uint32_t)__builtin_amdgcn_readlane((int)(valid ? cc : 0u), 0);
                 } else {
                     k1  = wave_max_u32(key);
                     k2  = wave_max_u32(key == k1 ? 0u : key);
-                    sum = wave_sum_u32(valid ? acc_c : 0u);
+                    sum = wave_sum_u32(valid ? cc : 0u);
                 }
                 uint32_t out = 0;
                 switch (lane) {
@@ -574,7 +581,7 @@ static __global__ void merge_rows_kernel(const uint16_t *A, const uint16_t *B, u
         const uint16_t tb = ib < nb ? rb[1 + 2 * ib] : (uint16_t)0xFFFF;
         if (ib >= nb || (ia < na && ta < tb))      { t = ta; h = ra[2 + 2 * ia]; ia++; }
         else if (ia >= na || tb < ta)              { t = tb; h = rb[2 + 2 * ib]; ib++; }
-        else { t = ta; h = (uint16_t)(ra[2 + 2 * ia] + rb[2 + 2 * ib]); ia++; ib++; }
+        else { t = ta; h = (uint16_t)sat_u16((uint32_t)ra[2 + 2 * ia] + rb[2 + 2 * ib]); ia++; ib++; }
         tmp[1 + 2 * n] = t; tmp[2 + 2 * n] = h; n++;
     }
     tmp[0] = (uint16_t)n;

@@ -715,7 +715,7 @@ void mz_query_kernel(const MzArgs A)
             if (a.flags & 2u) {
                 uint16_t *row = a.sparse_rows + rd * row_len;
                 if (lane == 0) row[0] = (uint16_t)n_keep;
-                if (valid) { row[1 + 2 * rank] = (uint16_t)acc_t; row[2 + 2 * rank] = (uint16_t)acc_c; }
+                if (valid) { row[1 + 2 * rank] = (uint16_t)acc_t; row[2 + 2 * rank] = (uint16_t)sat_u16(acc_c); }
                 for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
             }
             if (a.flags & 1u) {
@@ -725,15 +725,15 @@ void mz_query_kernel(const MzArgs A)
                     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)acc_t, 0);
                     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)acc_c, 0);
                     const bool has = n_acc == 1u;
-                    o0 = has ? (c0 & 0xFFFFu) : 0u;
+                    o0 = has ? sat_u16(c0) : 0u;
                     o1 = has ? (t0 & 0xFFFFu) + 1u : 0u;
-                    o2 = has ? (c0 > 0xFFFFu ? 0xFFFFu : c0) : 0u;
+                    o2 = o0;
                 } else {
-                    const uint32_t cc  = acc_c > 0xFFFFu ? 0xFFFFu : acc_c;
+                    const uint32_t cc  = sat_u16(acc_c);
                     const uint32_t key = valid ? ((cc << 16) | (0xFFFFu - (acc_t & 0xFFFFu))) : 0u;
                     const uint32_t k1  = wave_max_u32(key);
                     const uint32_t k2  = wave_max_u32(key == k1 ? 0u : key);
-                    const uint32_t sum = wave_sum_u32(valid ? acc_c : 0u);
+                    const uint32_t sum = wave_sum_u32(valid ? cc : 0u);
                     o0 = sum & 0xFFFFu;
                     o1 = k1 ? (0xFFFFu - (k1 & 0xFFFFu)) + 1u : 0u;
                     o2 = k1 >> 16;

@@ -504,7 +504,9 @@ void orc_query_batch(const orc_db *db, int k, uint32_t num_targets,
         row[0] = (uint16_t)keep;
         for (uint32_t i = 0; i < keep; i++) {
             row[1 + 2 * i] = touched[i];
-            row[2 + 2 * i] = (uint16_t)hits[touched[i]];
+            /* counts saturate at 65535 in every output (ours, DESIGN.md 7: the reference's packed
+             * u16 atomics carry into the neighbouring target there, :1104-1108) */
+            row[2 + 2 * i] = (uint16_t)(hits[touched[i]] > 0xFFFFu ? 0xFFFFu : hits[touched[i]]);
         }
         for (uint32_t i = 0; i < nt; i++) hits[touched[i]] = 0;
     }
@@ -531,7 +533,8 @@ void orc_merge_rows(const uint16_t *a, const uint16_t *b, size_t row_len, size_t
             } else if (ia >= na || rb[1 + 2 * ib] < ra[1 + 2 * ia]) {
                 t = rb[1 + 2 * ib]; h = rb[2 + 2 * ib]; ib++;
             } else {
-                t = ra[1 + 2 * ia]; h = (uint16_t)(ra[2 + 2 * ia] + rb[2 + 2 * ib]); ia++; ib++;
+                uint32_t s = (uint32_t)ra[2 + 2 * ia] + rb[2 + 2 * ib];      /* saturating, as above */
+                t = ra[1 + 2 * ia]; h = (uint16_t)(s > 0xFFFFu ? 0xFFFFu : s); ia++; ib++;
             }
             w[1 + 2 * n] = t; w[2 + 2 * n] = h; n++;
         }

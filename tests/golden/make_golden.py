@@ -113,9 +113,36 @@ def db_fixture(tmp, variant, exe, k, htsize, seed):
     print("db_%s.npz written: %d stored k-mers, %d lookups, %d found" % (variant, stored, q.size, sum(found)))
 
 
+def config0_targets(tmp):
+    """BASELINE configs[0] plumbing: files-to-taxonomy table -> targets.txt through the reference's
+    getTargetsDef (src/getTargetsDef.cc:38-96, run by scripts/set_targets.sh:117).  The input table
+    is ours (three genome files of the toy database, one file without taxonomy, one with an UNKNOWN
+    species); the outputs for rank 0 (species) and rank 1 (genus) and files_excluded.txt are the
+    reference's."""
+    rows = [
+        "Custom/genome0.fa\t511145\t562\t561\t543\t91347\t1236\t1224",
+        "Custom/genome1.fa,93061,1280,1279,90964,1385,91061,1239",
+        "Custom/plasmid_x.fa -1 -1 -1 -1 -1 -1 -1",
+        "Custom/genome2.fa\t224308\t1423\t1386\t186817\t1385\t91061\t1239",
+        "Custom/unplaced.fa\t12345\tUNKNOWN\t1386\t186817\t1385\t91061\t1239",
+    ]
+    d = os.path.join(OUT, "config0")
+    os.makedirs(d, exist_ok=True)
+    src = os.path.join(d, "custom.fileToTaxIDs")
+    open(src, "w").write("\n".join(rows) + "\n")
+    for rank in (0, 1):
+        out = run([os.path.join(REF, "ref_getTargetsDef"), src, str(rank)], cwd=tmp)
+        open(os.path.join(d, "targets_rank%d.txt" % rank), "w").write(out)
+    open(os.path.join(d, "files_excluded.txt"), "w").write(open(os.path.join(tmp, "files_excluded.txt")).read())
+    print("config0/: targets_rank0.txt, targets_rank1.txt, files_excluded.txt written")
+
+
 def main():
     full = "--full" in sys.argv
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        config0_targets(tmp)
+        if "--config0-only" in sys.argv:
+            return
         kmer_vectors(tmp)
         db_fixture(tmp, "light_k27", "ref_ht_light", 27, 57777779, 11)
         if full:

@@ -82,3 +82,39 @@ def test_full_size_table_properties(world):
         db.result_rows_device(r0, out, n, stream=st)
         torch.cuda.synchronize()
     assert torch.equal(out, fin_t)
+
+
+def test_eight_shards_with_paired_250bp_reads_equal_unsharded(world):
+    """BASELINE configs[3]/[4] shape on one card: the full-size table as 8 bucket-range shards played
+    in turn (CuClarkDB.cu:552-559), every shard sees every read (:842-851), 2 x 250 bp pairs joined
+    into one two-part read (file.cc:250: 501 nt, 66 containers, 440 k-mers); rows merged in shard
+    order, top-2 on the merged rows == the fused single-table result."""
+    import torch
+    from jn_cuclark_amd import CuClarkDB, synth_gpu
+    dev, genomes, raw, _ = world
+    n = 200_000
+    p1, c1 = synth_gpu.make_reads(genomes, n, 250, seed=521)
+    _, c2 = synth_gpu.make_reads(genomes, n, 250, seed=522)
+    per = c1.numel() // n                                        # [250][32 containers]
+    con = torch.cat([c1.view(n, per), c2.view(n, per)], dim=1).reshape(-1).contiguous()
+    rp = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (2 * per)).to(torch.int32)
+    reads = (rp, con, None, n)
+    fin_t, _ = _classify(dev, raw, reads)
+    fin = fin_t.cpu().numpy().view(np.uint16)
+    assert (fin[: n // 2, 0] > 250).mean() > 0.5                 # both mates hit
+    acc = None
+    for s in range(8):
+        a, b = HT * s // 8, HT * (s + 1) // 8
+        rows, info = _classify(dev, raw, reads, shard=(a, b), rows=True)
+        assert info["shard_begin"] == a and info["shard_end"] == b
+        if acc is None:
+            acc = rows
+        else:
+            with CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=15) as db:
+                db.merge_rows_device(acc, rows, acc, n, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+    with CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=15) as db:
+        out = torch.zeros((n, 5), dtype=torch.int16, device=dev)
+        db.result_rows_device(acc, out, n, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    assert torch.equal(out, fin_t)

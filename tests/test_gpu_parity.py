@@ -182,10 +182,12 @@ def test_sharded_db_merge_result_equals_unsharded(gpu, oracle, shards):
     assert np.array_equal(fin.cpu().numpy().view(np.uint16), want)
 
 
-def test_light_table_k27_against_reference_golden(gpu, oracle, golden_dir):
-    """HTSIZE 57777779, k=27: the database the REFERENCE's own code built, and the
-    lookups the reference's hTable::find answered (tests/golden/db_light_k27.npz)"""
-    g = np.load(os.path.join(golden_dir, "db_light_k27.npz"), allow_pickle=False)
+@pytest.mark.parametrize("fixture,maxhits", [("db_light_k27.npz", 23), ("db_full_k31.npz", 15)])
+def test_reference_built_tables_against_reference_find(gpu, oracle, golden_dir, fixture, maxhits):
+    """The databases the REFERENCE's own code built and the lookups the reference's hTable::find
+    answered (hashTable_hh.hh:358-396; fixtures by tests/golden/make_golden.py): cuCLARK-l's
+    HTSIZE 57777779 / k=27 and the metric's own HTSIZE 1610612741 / k=31, on both indexes."""
+    g = np.load(os.path.join(golden_dir, fixture), allow_pickle=False)
     k, ht = int(g["k"]), int(g["htsize"])
     sz = np.zeros(ht, dtype=np.uint8)
     sz[g["nonzero_buckets"]] = g["nonzero_sizes"]
@@ -195,9 +197,11 @@ def test_light_table_k27_against_reference_golden(gpu, oracle, golden_dir):
     for j in range(k):
         codes[:, j] = ((q >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)).astype(np.uint8)
     rp, con = synth.pack_uniform(codes)
-    with _open(gpu, sz, g["keys"], g["labels"], k=k, ht=ht, maxhits=23, ntargets=3) as db:
+    with _open(gpu, sz, g["keys"], g["labels"], k=k, ht=ht, maxhits=maxhits, ntargets=3) as db:
         got = db.classify(rp, con)
+        # the same k-mers as ONE long read per 1000 (consecutive positions share minimizers / steps)
     found = g["query_found"].astype(bool)
+    assert found.sum() > 5000 and (~found).sum() > 5000
     assert np.array_equal(got[:, 2] > 0, found)
     assert np.array_equal(got[found, 1] - 1, g["query_label"][found])
     assert np.all(got[found, 0] == 1)
@@ -390,3 +394,71 @@ def test_random_ragged_batches(gpu, oracle, seed):
     assert np.array_equal(rows, want_rows)
     assert np.array_equal(got, oracle.result_rows(want_rows))
     assert (got[:, 2] > 0).sum() > 400
+
+
+def test_counts_saturate_at_65535_in_every_output(gpu, oracle):
+    """One rule for per-target counts above 65 535 (the reference's packed u16 atomics
+    carry into the neighbouring target there, CuClarkDB.cu:1104-1108): they saturate -- in the fused
+    final row, in the sparse row, through result_rows, and through a 2-shard merge whose halves are
+    each below the limit.  A contig-like read with > 66 000 hits on one target (two passes over the
+    same genome) next to a second target with a few hits."""
+    import torch
+    genomes, sz, ky, lb = small_db(glen=40000, n_targets=3, shared=0)
+    g0 = synth.codes_to_ascii(genomes[0][:35000])
+    seq = g0 + b"N" + g0 + b"N" + synth.codes_to_ascii(genomes[2][100:400])
+    text = synth.fasta_text([b"contig", b"plain"], [seq, synth.codes_to_ascii(genomes[1][:150])], width=100)
+    _, rp, con = pack_with_oracle(oracle, text, K)
+    odb = oracle.OracleDB.from_arrays(HT, sz, ky, lb)
+    want_rows, _ = odb.query_rows(K, rp, con, 15)
+    want = oracle.result_rows(want_rows)
+    assert want_rows[0, 0] == 2 and want_rows[0, 2] == 65535 and 200 < want_rows[0, 4] <= 280
+    assert want[0, 2] == 65535 and want[0, 1] == 1 and want[0, 0] == (65535 + int(want_rows[0, 4])) % 65536
+    n = rp.size - 1
+    dev = torch.device("cuda:0")
+    rp_t = torch.from_numpy(rp.view(np.int32)).to(dev)
+    con_t = torch.from_numpy(con.view(np.int16)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    with _open(gpu, sz, ky, lb) as db:
+        got, rows = db.classify(rp, con, extended=True)                 # fused final + rows of one launch
+        assert np.array_equal(rows, want_rows) and np.array_equal(got, want)
+        fin_t = torch.zeros((n, 5), dtype=torch.int16, device=dev)
+        db.result_rows_device(torch.from_numpy(rows.view(np.int16)).to(dev), fin_t, n, stream=st)
+        torch.cuda.synchronize()
+        assert np.array_equal(fin_t.cpu().numpy().view(np.uint16), want)      # rows -> result_rows
+    # two bucket-range shards, each with fewer than 65 536 hits on target 0, merged
+    half = HT // 2
+    parts = []
+    for a, b in ((0, half), (half, HT)):
+        pr_want, _ = odb.query_rows(K, rp, con, 15, part=(a, b))
+        assert 20000 < pr_want[0, 2] < 50000
+        with _open(gpu, sz, ky, lb, shard=(a, b)) as db:
+            rt = torch.zeros((n, db.row_len), dtype=torch.int16, device=dev)
+            db.query_device(rp_t, con_t, rows_t=rt, stream=st)
+            torch.cuda.synchronize()
+            assert np.array_equal(rt.cpu().numpy().view(np.uint16), pr_want)
+            parts.append(rt)
+    assert np.array_equal(oracle.merge_rows(parts[0].cpu().numpy().view(np.uint16), parts[1].cpu().numpy().view(np.uint16)), want_rows)
+    with _open(gpu, sz, ky, lb) as db:
+        db.merge_rows_device(parts[0], parts[1], parts[0], n, stream=st)
+        fin_t = torch.zeros((n, 5), dtype=torch.int16, device=dev)
+        db.result_rows_device(parts[0], fin_t, n, stream=st)
+        torch.cuda.synchronize()
+    assert np.array_equal(parts[0].cpu().numpy().view(np.uint16), want_rows)
+    assert np.array_equal(fin_t.cpu().numpy().view(np.uint16), want)
+
+
+def test_sharded_kernel_with_integer_division_remainder(gpu, oracle, index_mode):
+    """the shard filter's `c mod HTSIZE`: the floating-point remainder needs HTSIZE > 1024 and
+    4^k <= HTSIZE * 2^32; a 1009-bucket table takes the 64-bit magic division instead"""
+    k, ht = 21, 1009
+    genomes = synth.toy_genomes(5, 3000, seed=17, shared=100)
+    sz, ky, lb = synth.genome_db(genomes, k, ht)
+    names, seqs = mixed_fasta(genomes, k, seed=4, n=800)
+    _, rp, con = pack_with_oracle(oracle, synth.fasta_text(names, seqs), k)
+    odb = oracle.OracleDB.from_arrays(ht, sz, ky, lb)
+    for a, b in ((0, 400), (400, 1009)):
+        want_rows, _ = odb.query_rows(k, rp, con, 15, part=(a, b))
+        with _open(gpu, sz, ky, lb, k=k, ht=ht, ntargets=5, shard=(a, b)) as db:
+            _, rows = db.classify(rp, con, extended=True)
+        assert np.array_equal(rows, want_rows)
+        assert (want_rows[:, 0] > 0).sum() > 200
