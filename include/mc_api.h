@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MC_API_VERSION 1
+#define MC_API_VERSION 2
 
 enum {
     MC_OK          =  0,
@@ -67,7 +67,25 @@ typedef struct mc_db_info {
     uint32_t line_bytes;      /* bucket line size chosen at load (64 or 128)         */
     uint32_t line_capacity;   /* k-mers per line                                     */
     uint64_t device_bytes;    /* HBM held by the database                            */
+    /* --- version 2 --- */
+    uint32_t index_kind;      /* MC_INDEX_BUCKET_LINES or MC_INDEX_MINIMIZER: which in-HBM index was built */
+    uint32_t index_fallback;  /* 1: the minimizer index was wanted but did not fit; bucket lines were built
+                                 (also reported on stderr)                                                 */
+    uint32_t part, n_parts;   /* line-range part of a table spread over n_parts contexts (0 of 1 = whole)  */
+    uint64_t n_keys_owned;    /* k-mers this context answers for (= n_keys unless n_parts > 1)            */
+    /* minimizer index only (for it n_overflow_buckets = extra lines, n_overflow_keys = spilled k-mers): */
+    uint64_t n_lines;             /* primary lines of the whole table                  */
+    uint64_t line_begin, line_end;/* primary lines held here                           */
+    uint64_t n_extra_lines;       /* lines chained behind overflowing primary lines    */
+    uint64_t n_side_lines;        /* side table (k-mers of crowded minimizers)         */
+    uint64_t n_lines_overflowing; /* primary lines with more k-mers than slots         */
+    uint64_t n_spilled_keys;      /* k-mers in the side table                          */
+    uint32_t largest_line;        /* most k-mers that share one primary line           */
+    uint32_t reserved_;
 } mc_db_info;
+
+#define MC_INDEX_BUCKET_LINES 0u
+#define MC_INDEX_MINIMIZER    1u
 
 typedef struct mc_stats {
     uint64_t reads;               /* reads classified since mc_open                  */
@@ -109,6 +127,32 @@ int mc_load_db_host(mc_ctx *ctx, const uint8_t *sz, const void *keys, int key_by
 int mc_load_db_device(mc_ctx *ctx, const uint8_t *d_sz, const void *d_keys, int key_bytes,
                       const uint16_t *d_labels, uint64_t n_keys,
                       uint64_t shard_begin, uint64_t shard_end);
+
+/* Line-range part of a table that is spread over n_parts contexts (GPUs): this context keeps the k-mers
+ * whose minimizer line falls into range `part` of the line space (mc_minimizer.hpp), streams the WHOLE
+ * files through the build kernels and drops the rest.  Replaces the same members as mc_load_db for the
+ * multi-device case (the reference gives device d the bucket range m_partPointer[d..d+1],
+ * CuClarkDB.cu:552-559, and every device every read batch, :842-851).  Where the reference's bucket ranges
+ * scatter the consecutive k-mers of a read over all devices (every device fetches nearly every line), a
+ * line range keeps a read's run on ONE device: fetch, match and scoring divide by n_parts.  The per-read
+ * rows of the parts add up exactly like those of bucket ranges (mc_merge_result_device).  Needs k >= 16. */
+int mc_load_db_part(mc_ctx *ctx, const char *base, int key_bytes, uint32_t sampling,
+                    uint32_t part, uint32_t n_parts);
+
+/* The same index built from a table the caller produces in bucket-order CHUNKS (any size), fed twice:
+ *   mc_index_begin -> mc_index_add_* for every chunk -> mc_index_next_pass -> the same chunks again
+ *   -> mc_index_end.
+ * Neither the raw arrays of the whole table nor a second copy are ever resident next to the lines
+ * (CuClarkDB::read budgets pinned host memory for exactly that, CuClarkDB.cu:516-540).  n_keys_total =
+ * k-mers of the whole table (all parts): it sizes the line space and must agree between the parts.
+ * A chunk = buckets [bucket_begin, bucket_end): sz has one byte per bucket, keys/labels n_keys entries. */
+int mc_index_begin(mc_ctx *ctx, uint64_t n_keys_total, uint32_t part, uint32_t n_parts);
+int mc_index_add_device(mc_ctx *ctx, const uint8_t *d_sz, const void *d_keys, int key_bytes,
+                        const uint16_t *d_labels, uint64_t n_keys, uint64_t bucket_begin, uint64_t bucket_end);
+int mc_index_add_host(mc_ctx *ctx, const uint8_t *sz, const void *keys, int key_bytes,
+                      const uint16_t *labels, uint64_t n_keys, uint64_t bucket_begin, uint64_t bucket_end);
+int mc_index_next_pass(mc_ctx *ctx);
+int mc_index_end(mc_ctx *ctx);
 
 int mc_get_db_info(mc_ctx *ctx, mc_db_info *out);
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);
@@ -161,6 +205,13 @@ int mc_merge_rows_device(mc_ctx *ctx, const uint16_t *d_a, const uint16_t *d_b,
 /* resultKernel: sparse rows -> final rows.  CuClarkDB.cu:1361-1411. */
 int mc_result_rows_device(mc_ctx *ctx, const uint16_t *d_rows, uint64_t n_reads,
                           uint16_t *d_final_rows, void *stream);
+
+/* mergeKernel over all shards at once + resultKernel: d_srcs[0..n_srcs) (a HOST array of device pointers,
+ * 1 <= n_srcs <= 16) each hold n_reads sparse rows; writes the merged rows (d_out_rows, may be NULL) and the
+ * final rows (d_final_rows, may be NULL).  Equal to folding the sources pairwise with mc_merge_rows_device
+ * and then mc_result_rows_device.  CuClarkDB.cu:909-928 (merge tree) + :963-968. */
+int mc_merge_result_device(mc_ctx *ctx, const uint16_t *const *d_srcs, uint32_t n_srcs, uint64_t n_reads,
+                           uint16_t *d_out_rows, uint16_t *d_final_rows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,84 @@
+/*
+ * mc_group.h -- several GPUs behind ONE handle, in one process (part of libmcclark.so).
+ *
+ * The reference's CuClarkDB object drives all devices itself: it discovers them and enables peer
+ * access (src/CuClarkDB.cu:118-215), cuts the table into per-device bucket ranges sized by free memory
+ * (:516-559), sends EVERY read batch to EVERY device (:842-851), pulls the partial sparse rows to device 0
+ * through a blocking cudaMemcpyPeer binary tree with a mergeKernel per hop (:909-928), runs resultKernel
+ * there (:963-968), and cycles table parts through the devices when even all of them together are too small
+ * (swapDbParts, :775-815).  `-d <n>` selects how many devices (src/main.cc:43-69; 0 = all,
+ * CuClarkDB.cu:146-150).  mc_group is that object for MI355X:
+ *
+ *   replicas   the table fits one GPU (288 GB: every table the reference targets, up to ~12e9 k-mers):
+ *              every GPU holds all of it, batches are dealt round-robin, no exchange at all;
+ *   shards     it does not: GPU g holds line range g of the minimizer index (mc_load_db_part; bucket
+ *              ranges as in the reference when that index is not available), every GPU gets every batch,
+ *              each produces sparse rows for all reads; rows are exchanged device-to-device as a
+ *              reduce-scatter by read range (GPU j receives every GPU's rows for read range j:
+ *              hipMemcpyPeerAsync over xGMI, all links busy once, nothing funnels into device 0), merged
+ *              by one k-way kernel and top-2 on the owner, which copies its range of final rows to the
+ *              host.  Integer rows: the result is bit-identical to the unsharded run for any device count.
+ *
+ * The host sees the same batch interface as with one context (mc_api.h): pinned input and result
+ * buffers owned by the library, submit, wait.  Plain C ABI; errors via mc_last_error().
+ */
+#ifndef MC_GROUP_H
+#define MC_GROUP_H
+
+#include "mc_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mc_group mc_group;
+
+#define MC_GROUP_AUTO     0   /* replicas if the table fits every device, else shards */
+#define MC_GROUP_REPLICAS 1
+#define MC_GROUP_SHARDS   2
+
+typedef struct mc_group_info {
+    uint32_t n_members;        /* contexts (normally one per device)                              */
+    uint32_t mode;             /* MC_GROUP_REPLICAS or MC_GROUP_SHARDS, as chosen at load          */
+    uint32_t shard_kind;       /* 0 = none, 1 = minimizer line ranges, 2 = bucket ranges           */
+    uint32_t peer_access;      /* 1: every pair of distinct devices has direct peer access         */
+    uint64_t n_keys;           /* k-mers of the table                                              */
+    uint64_t device_bytes_max; /* largest per-device share of the database in HBM                  */
+    uint64_t bytes_needed_one; /* estimate used for the choice: HBM a full replica needs           */
+    uint64_t bytes_free_min;   /* smallest free HBM among the devices when the choice was made     */
+} mc_group_info;
+
+/* replaces: CuClarkDB::CuClarkDB device discovery + peer access (CuClarkDB.cu:118-215).
+ * devices == NULL: the first n_devices visible devices, n_devices == 0: all of them (:146-150).
+ * A device may be listed more than once (several contexts on one card: how the sharded path is
+ * rehearsed and tested on a one-GPU box); with devices == NULL the environment variable
+ * MC_GROUP_DEVICES=0,0,1 supplies such a list.  MC_ENODEVICE when fewer are visible than asked for (:140-144). */
+int mc_group_open(mc_group **out, const int *devices, uint32_t n_devices, uint32_t k, uint64_t htsize,
+                  uint32_t num_targets, uint32_t maxhits);
+int mc_group_close(mc_group *g);
+
+/* replaces: CuClarkDB::read for all devices (CuClarkDB.cu:463-770), incl. the memory budget that
+ * decides how the table is cut (:516-559).  The files are streamed once per build pass and fed to all
+ * devices.  mode: MC_GROUP_AUTO / _REPLICAS / _SHARDS (environment MC_GROUP_MODE=replicas|shards
+ * overrides AUTO; MC_GROUP_HBM_BYTES caps the per-device memory the choice assumes). */
+int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t sampling, int mode);
+int mc_group_get_info(mc_group *g, mc_group_info *out);
+/* the member contexts, for mc_get_db_info / mc_get_stats */
+int mc_group_member(mc_group *g, uint32_t i, mc_ctx **out);
+
+/* as mc_alloc_batches / mc_batch_buffers / mc_submit / mc_wait / mc_free_batches, for the group:
+ * replaces malloc, readyBatch + queryBatch, waitForBatch, freeBatchMemory (CuClarkDB.cu:321-421,
+ * :820-987, :441-446, :284-316) */
+int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, uint64_t max_containers,
+                           int want_rows);
+int mc_group_batch_buffers(mc_group *g, uint32_t batch, uint32_t **reads_ptr, uint16_t **containers,
+                           uint16_t **final_rows, uint16_t **sparse_rows);
+int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_containers, uint32_t flags);
+int mc_group_wait(mc_group *g, uint32_t batch);
+int mc_group_sync(mc_group *g);
+int mc_group_free_batches(mc_group *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_GROUP_H */

@@ -9,17 +9,21 @@
 // The class declaration stays the reference's, so this file cannot add members: the
 // per-object state lives in a side table keyed by `this`.  No algorithm lives here --
 // only the mapping between the two interfaces:
-//   ctor            -> mc_open          (HTSIZE / MAXHITS from the reference's parameters.hh)
-//   read            -> mc_load_db       (false when the files are missing, as the reference)
-//   malloc          -> mc_alloc_batches + mc_batch_buffers; the two whole-file result tables
+//   ctor            -> mc_group_open    (numDevices as the reference: 0 = all, CuClarkDB.cu:146-150;
+//                                        HTSIZE / MAXHITS from the reference's parameters.hh)
+//   read            -> mc_group_load_db (false when the files are missing, as the reference; replicas when
+//                                        the table fits one GPU, shards + device-to-device row exchange
+//                                        when it does not, include/mc_group.h)
+//   malloc          -> mc_group_alloc_batches + mc_group_batch_buffers; the two whole-file result tables
 //                      the host indexes by global read number are plain pinned-size host arrays
 //   readyBatch      -> remembered sizes
-//   queryBatch      -> mc_submit        (always returns true: the table is resident, one cycle)
+//   queryBatch      -> mc_group_submit  (always returns true: the table is resident, one cycle)
 //   swapDbParts     -> one cycle, then false (reference :775-815 cycles DB parts)
-//   waitForBatch    -> mc_wait + copy of the batch's rows into the whole-file tables
-//   sync / freeBatchMemory -> mc_sync / mc_free_batches
+//   waitForBatch    -> mc_group_wait + copy of the batch's rows into the whole-file tables
+//   sync / freeBatchMemory -> mc_group_sync / mc_group_free_batches
 #include "CuClarkDB.cuh"          // the reference's header, unchanged
 #include "mc_api.h"
+#include "mc_group.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +35,7 @@
 namespace {
 
 struct State {
-    mc_ctx *ctx = nullptr;
+    mc_group *grp = nullptr;
     int cycles_to_do = 1;
     bool extended = false;
     size_t row_len = 0, final_len = 0;
@@ -67,17 +71,18 @@ CuClarkDB<HKMERr>::CuClarkDB(const size_t _numDevices, const uint8_t _k, const s
     int n = 0;
     if (mc_device_count(&n) != MC_OK || n < 1) { std::cerr << "No HIP devices found. Abort.\n"; exit(1); }
     if ((size_t)n < _numDevices) { std::cerr << _numDevices << " devices requested. Insufficient devices found. Abort.\n"; exit(1); }
-    m_numDevices = 1;                      // one context; more GPUs = more processes
+    m_numDevices = _numDevices ? _numDevices : (size_t)n;          // 0 = all (reference :146-150)
     m_dbParts = 1; m_dbPartsPerDevice = 1; m_cyclesPerDevice = 1; m_cyclesToDo = 1;
     State &s = st(this);
-    check(mc_open(&s.ctx, 0, _k, (uint64_t)HTSIZE, (uint32_t)_numTargets, (uint32_t)MAXHITS), "mc_open");
+    check(mc_group_open(&s.grp, nullptr, (uint32_t)_numDevices, _k, (uint64_t)HTSIZE, (uint32_t)_numTargets, (uint32_t)MAXHITS),
+          "mc_group_open");
 }
 
 template <typename HKMERr>
 CuClarkDB<HKMERr>::~CuClarkDB()
 {
     State &s = st(this);
-    mc_close(s.ctx);
+    mc_group_close(s.grp);
     std::lock_guard<std::mutex> lk(g_mu);
     g_state.erase(this);
 }
@@ -86,13 +91,13 @@ template <typename HKMERr>
 bool CuClarkDB<HKMERr>::read(const char *_filename, size_t &_fileSize, size_t &_dbParts, const ITYPE &_modCollision)
 {
     State &s = st(this);
-    const int rc = mc_load_db(s.ctx, _filename, (int)sizeof(HKMERr), _modCollision, 0, 0);
+    const int rc = mc_group_load_db(s.grp, _filename, (int)sizeof(HKMERr), _modCollision, MC_GROUP_AUTO);
     if (rc == MC_EIO) { std::cerr << mc_last_error() << std::endl; return false; }
-    check(rc, "mc_load_db");
-    mc_db_info info;
-    check(mc_get_db_info(s.ctx, &info), "mc_get_db_info");
-    _fileSize = info.device_bytes;
-    _dbParts = 1;
+    check(rc, "mc_group_load_db");
+    mc_group_info info;
+    check(mc_group_get_info(s.grp, &info), "mc_group_get_info");
+    _fileSize = info.device_bytes_max;
+    _dbParts = 1;                          // everything is resident: one cycle, however many devices
     s.cycles_to_do = 1;
     std::cerr << (m_verbose ? "DB loaded in HBM.\n" : "CuCLARK initialized.\n");
     return true;
@@ -111,12 +116,12 @@ size_t CuClarkDB<HKMERr>::malloc(size_t _numReads, size_t _maxReads, size_t _max
     s.index = _indexBatches;
     s.n_reads.assign(m_numBatches, 0);
     s.n_con.assign(m_numBatches, 0);
-    check(mc_alloc_batches(s.ctx, (uint32_t)m_numBatches, _maxReads ? _maxReads : 1, _maxReadsInContainers,
-                           _isExtended ? 1 : 0), "mc_alloc_batches");
+    check(mc_group_alloc_batches(s.grp, (uint32_t)m_numBatches, _maxReads ? _maxReads : 1, _maxReadsInContainers,
+                                 _isExtended ? 1 : 0), "mc_group_alloc_batches");
     _readsPointer.resize(m_numBatches);
     _readsInCon.resize(m_numBatches);
     for (size_t b = 0; b < m_numBatches; b++)
-        check(mc_batch_buffers(s.ctx, (uint32_t)b, &_readsPointer[b], &_readsInCon[b], nullptr, nullptr), "mc_batch_buffers");
+        check(mc_group_batch_buffers(s.grp, (uint32_t)b, &_readsPointer[b], &_readsInCon[b], nullptr, nullptr), "mc_group_batch_buffers");
     _fullResults = nullptr;
     if (_isExtended) _fullResults = (RESULTS *)std::calloc(_numReads * _resultRowSize + 1, sizeof(RESULTS));
     _finalResults = (RESULTS *)std::calloc(_numReads * _finalResultsRowSize + 1, sizeof(RESULTS));
@@ -129,7 +134,7 @@ template <typename HKMERr>
 void CuClarkDB<HKMERr>::freeBatchMemory()
 {
     State &s = st(this);
-    mc_free_batches(s.ctx);
+    mc_group_free_batches(s.grp);
     std::free(s.full); std::free(s.final_);
     s.full = s.final_ = nullptr;
 }
@@ -137,7 +142,7 @@ void CuClarkDB<HKMERr>::freeBatchMemory()
 template <typename HKMERr>
 bool CuClarkDB<HKMERr>::sync()
 {
-    check(mc_sync(st(this).ctx), "mc_sync");
+    check(mc_group_sync(st(this).grp), "mc_group_sync");
     return true;
 }
 
@@ -154,8 +159,8 @@ template <typename HKMERr>
 bool CuClarkDB<HKMERr>::queryBatch(const size_t _batchId, const bool _isExtended, const bool)
 {
     State &s = st(this);
-    check(mc_submit(s.ctx, (uint32_t)_batchId, s.n_reads[_batchId], s.n_con[_batchId],
-                    MC_F_FINAL | (_isExtended ? MC_F_ROWS : 0)), "mc_submit");
+    check(mc_group_submit(s.grp, (uint32_t)_batchId, s.n_reads[_batchId], s.n_con[_batchId],
+                          MC_F_FINAL | (_isExtended ? MC_F_ROWS : 0)), "mc_group_submit");
     return true;
 }
 
@@ -172,9 +177,9 @@ template <typename HKMERr>
 bool CuClarkDB<HKMERr>::waitForBatch(size_t batchId)
 {
     State &s = st(this);
-    check(mc_wait(s.ctx, (uint32_t)batchId), "mc_wait");
+    check(mc_group_wait(s.grp, (uint32_t)batchId), "mc_group_wait");
     uint16_t *fin = nullptr, *rows = nullptr;
-    check(mc_batch_buffers(s.ctx, (uint32_t)batchId, nullptr, nullptr, &fin, &rows), "mc_batch_buffers");
+    check(mc_group_batch_buffers(s.grp, (uint32_t)batchId, nullptr, nullptr, &fin, &rows), "mc_group_batch_buffers");
     const size_t n = s.n_reads[batchId], at = s.index[batchId];
     std::memcpy(s.final_ + at * s.final_len, fin, n * s.final_len * sizeof(RESULTS));
     if (s.extended) std::memcpy(s.full + at * s.row_len, rows, n * s.row_len * sizeof(RESULTS));

@@ -21,7 +21,16 @@ class McDbInfo(C.Structure):
     _fields_ = [("htsize", C.c_uint64), ("shard_begin", C.c_uint64), ("shard_end", C.c_uint64),
                 ("n_keys", C.c_uint64), ("n_overflow_buckets", C.c_uint64),
                 ("n_overflow_keys", C.c_uint64), ("line_bytes", C.c_uint32),
-                ("line_capacity", C.c_uint32), ("device_bytes", C.c_uint64)]
+                ("line_capacity", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("index_kind", C.c_uint32), ("index_fallback", C.c_uint32),
+                ("part", C.c_uint32), ("n_parts", C.c_uint32), ("n_keys_owned", C.c_uint64),
+                ("n_lines", C.c_uint64), ("line_begin", C.c_uint64), ("line_end", C.c_uint64),
+                ("n_extra_lines", C.c_uint64), ("n_side_lines", C.c_uint64),
+                ("n_lines_overflowing", C.c_uint64), ("n_spilled_keys", C.c_uint64),
+                ("largest_line", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+MC_INDEX_BUCKET_LINES, MC_INDEX_MINIMIZER = 0, 1
 
 
 class McStats(C.Structure):
@@ -45,6 +54,12 @@ SYMBOLS = [
     ("mc_load_db", _i, [_vp, C.c_char_p, _i, _u32, _u64, _u64]),
     ("mc_load_db_host", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
     ("mc_load_db_device", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
+    ("mc_load_db_part", _i, [_vp, C.c_char_p, _i, _u32, _u32, _u32]),
+    ("mc_index_begin", _i, [_vp, _u64, _u32, _u32]),
+    ("mc_index_add_device", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
+    ("mc_index_add_host", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
+    ("mc_index_next_pass", _i, [_vp]),
+    ("mc_index_end", _i, [_vp]),
     ("mc_get_db_info", _i, [_vp, C.POINTER(McDbInfo)]),
     ("mc_get_stats", _i, [_vp, C.POINTER(McStats)]),
     ("mc_alloc_batches", _i, [_vp, _u32, _u64, _u64, _i]),
@@ -56,6 +71,7 @@ SYMBOLS = [
     ("mc_query_device", _i, [_vp, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
     ("mc_merge_rows_device", _i, [_vp, _vp, _vp, _u64, _vp, _vp]),
     ("mc_result_rows_device", _i, [_vp, _vp, _u64, _vp, _vp]),
+    ("mc_merge_result_device", _i, [_vp, C.POINTER(_vp), _u32, _u64, _vp, _vp, _vp]),
 ]
 
 

@@ -96,6 +96,35 @@ class CuClarkDB:
                                           _ptr(d_labels), int(d_keys.numel()), int(shard[0]), int(shard[1])))
         self._cycles_to_do = 1
 
+    def read_part(self, filename, part, n_parts, modCollision=1, key_bytes=4):
+        """Line-range part `part` of `n_parts` of the table in the files (mc_load_db_part): what one GPU
+        of a multi-GPU job holds; every part sees every read batch, rows add up (merge_result_device)."""
+        rc = self._lib.mc_load_db_part(self._h, filename.encode(), key_bytes, int(modCollision), int(part), int(n_parts))
+        if rc == -2:      # MC_EIO
+            return False
+        check(rc)
+        self._cycles_to_do = 1
+        return True
+
+    def read_chunks(self, chunks, n_keys_total, part=0, n_parts=1, device=False):
+        """Streamed index build (mc_index_*): `chunks` is a callable returning an iterator of
+        (sz, keys, labels, bucket_begin, bucket_end) -- numpy arrays, or torch tensors on this GPU when
+        device=True -- and is called twice (the table is fed once per pass)."""
+        check(self._lib.mc_index_begin(self._h, int(n_keys_total), int(part), int(n_parts)))
+        for p in range(2):
+            for sz, keys, labels, b0, b1 in chunks():
+                if device:
+                    check(self._lib.mc_index_add_device(self._h, _ptr(sz), _ptr(keys), int(keys.element_size()),
+                                                        _ptr(labels), int(keys.numel()), int(b0), int(b1)))
+                else:
+                    sz = np.ascontiguousarray(sz, dtype=np.uint8)
+                    keys = np.ascontiguousarray(keys)
+                    labels = np.ascontiguousarray(labels, dtype=np.uint16)
+                    check(self._lib.mc_index_add_host(self._h, sz.ctypes.data, keys.ctypes.data, keys.dtype.itemsize,
+                                                      labels.ctypes.data, keys.size, int(b0), int(b1)))
+            check(self._lib.mc_index_next_pass(self._h) if p == 0 else self._lib.mc_index_end(self._h))
+        self._cycles_to_do = 1
+
     def db_info(self):
         info = McDbInfo()
         check(self._lib.mc_get_db_info(self._h, C.byref(info)))
@@ -185,6 +214,12 @@ class CuClarkDB:
     def merge_rows_device(self, a_t, b_t, out_t, n_reads, stream=None):
         check(self._lib.mc_merge_rows_device(self._h, _ptr(a_t), _ptr(b_t), int(n_reads), _ptr(out_t),
                                              C.c_void_p(stream) if stream else None))
+
+    def merge_result_device(self, srcs, n_reads, rows_t=None, final_t=None, stream=None):
+        """k-way merge of the sparse rows of up to 16 shards (+ top-2) in one launch"""
+        arr = (C.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+        check(self._lib.mc_merge_result_device(self._h, arr, len(srcs), int(n_reads), _ptr(rows_t), _ptr(final_t),
+                                               C.c_void_p(stream) if stream else None))
 
     def result_rows_device(self, rows_t, final_t, n_reads, stream=None):
         check(self._lib.mc_result_rows_device(self._h, _ptr(rows_t), int(n_reads), _ptr(final_t),

@@ -4,11 +4,8 @@
 //
 // There is NO CPU fallback in this library: without a gfx950 device every entry point
 // that needs one fails with MC_ENODEVICE / MC_EHIP.
-#include "../../include/mc_api.h"
-#include "mc_device.hpp"
+#include "mc_internal.hpp"
 #include "mc_minimizer.hpp"
-
-#include <hip/hip_runtime.h>
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -22,8 +19,10 @@
 #include <vector>
 
 namespace {
-
 thread_local std::string g_err;
+}
+
+namespace mcint {
 
 int fail(int code, const std::string &msg)
 {
@@ -31,91 +30,21 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
-#define HIPCHK(expr)                                                                        \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(MC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
-    } while (0)
-
-// Device temporaries of one API call: released when the call returns, on every path.
-struct Scope {
-    std::vector<void *> ptrs;
-    ~Scope() { for (void *p : ptrs) if (p) (void)hipFree(p); }
-    void add(void *p) { ptrs.push_back(p); }
-    void drop(void *p)      // release early (large temporaries), or after ownership moved on
-    {
-        for (auto &q : ptrs) if (q == p && p) { (void)hipFree(p); q = nullptr; }
-    }
-    void forget(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }
-};
-#define TMP_MALLOC(scope, ptr, bytes)                                                   \
-    do {                                                                                \
-        HIPCHK(hipMalloc(&(ptr), (bytes)));                                             \
-        (scope).add(ptr);                                                               \
-    } while (0)
-
-struct Batch {
-    uint32_t *h_ptr = nullptr;
-    uint16_t *h_con = nullptr;
-    uint16_t *h_final = nullptr;
-    uint16_t *h_rows = nullptr;
-    hipEvent_t ev = nullptr;
-    bool submitted = false;
-};
-
-struct Slot {
-    uint32_t *d_ptr = nullptr;
-    uint16_t *d_con = nullptr;
-    uint16_t *d_final = nullptr;
-    uint16_t *d_rows = nullptr;
-};
-
-} // namespace
-
-struct mc_ctx {
-    int device = 0;
-    uint32_t k = 0, num_targets = 0, maxhits = 0;
-    uint64_t htsize = 0;
-    mc::DivU64 div{};
-    bool wide = false;          // quotients need 64 bits (reference T64 regime: k = 32)
-    int n_cu = 0;
-
-    hipStream_t streams[2] = {nullptr, nullptr};
-
-    // database
-    bool db_loaded = false;
-    uint8_t *d_lines = nullptr;
-    void *d_ovf_keys = nullptr;
-    uint16_t *d_ovf_labels = nullptr;
-    mc_db_info info{};
-    int grid_blocks = 0;
-
-    // locality-aware index (mc_minimizer.hpp): the default for k >= 16; MC_INDEX=lines
-    // selects the direct bucket-line table instead (also the fallback when the minimizer
-    // lines do not fit in HBM)
-    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
-    uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
-    uint32_t mz_n_lines = 0, mz_m = 0;
-
-    unsigned long long *d_over = nullptr;
-
-    // batches
-    std::vector<Batch> batches;
-    Slot slots[2];
-    uint64_t max_reads = 0, max_con = 0;
-    bool want_rows = false;
-
-    mc_stats stats{};
-};
-
-namespace {
-
 int set_dev(mc_ctx *c)
 {
     HIPCHK(hipSetDevice(c->device));
     return MC_OK;
 }
+
+} // namespace mcint
+
+using mcint::fail;
+using mcint::set_dev;
+using mcint::Scope;
+using mcint::Batch;
+using mcint::Slot;
+
+namespace {
 
 void free_db(mc_ctx *c)
 {
@@ -124,8 +53,9 @@ void free_db(mc_ctx *c)
     if (c->d_ovf_labels) (void)hipFree(c->d_ovf_labels);
     if (c->d_mz_lines) (void)hipFree(c->d_mz_lines);
     if (c->d_mz_extra) (void)hipFree(c->d_mz_extra);
+    if (c->d_mz_side) (void)hipFree(c->d_mz_side);
     c->d_lines = nullptr; c->d_ovf_keys = nullptr; c->d_ovf_labels = nullptr;
-    c->d_mz_lines = nullptr; c->d_mz_extra = nullptr;
+    c->d_mz_lines = nullptr; c->d_mz_extra = nullptr; c->d_mz_side = nullptr;
     c->db_loaded = false;
 }
 
@@ -148,80 +78,61 @@ int query_occupancy(int &occ)
     return MC_OK;
 }
 
-// exclusive u32 scan on the device (per-workgroup sums scanned on the host); *total = sum
-int scan_u32_device(mc_ctx *c, const uint32_t *d_v, uint64_t n, uint32_t *d_out, uint64_t *total)
+// ---------------------------------------------------------------------------
+// minimizer index, built from bucket-order chunks in two passes (count, place)
+// ---------------------------------------------------------------------------
+void index_abort(mc_ctx *c)
 {
+    if (c->build.d_count) (void)hipFree(c->build.d_count);
+    c->build = mcint::IndexBuild();
+}
+
+// the minimizer index needs a minimizer space (canonical m-mers) well above the number of lines
+bool mz_eligible(const mc_ctx *c, uint64_t n_keys_total)
+{
+    const uint32_t mz_m = mc::mz::mmer_len(c->k);
+    return c->k >= 16 && mz_m >= 6 && (mz_m >= 20 || (1ull << (2 * mz_m - 1)) >= 4 * (n_keys_total / 6 + 1024));
+}
+
+int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts)
+{
+    if (n_parts < 1 || part >= n_parts) return fail(MC_EINVAL, "bad part / n_parts");
+    if (!mz_eligible(c, n_keys_total))
+        return fail(MC_EINVAL, "the minimizer index needs k >= 16 and a minimizer space above the line count");
+    free_db(c);
+    index_abort(c);
+    double per_line = 6.0;
+    if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
+    const uint64_t want = (uint64_t)((double)n_keys_total / per_line) + 1024;
+    if (want >= 0xFFFFFFF0ull) return fail(MC_EINVAL, "minimizer index: too many lines");
+    const uint32_t n_lines = (uint32_t)want;
+    c->mz_n_lines = n_lines;
+    c->mz_line0 = (uint32_t)((uint64_t)n_lines * part / n_parts);
+    c->mz_n_local = (uint32_t)((uint64_t)n_lines * (part + 1) / n_parts) - c->mz_line0;
+    c->mz_m = mc::mz::mmer_len(c->k);
+    c->info = mc_db_info{};
+    c->info.part = part; c->info.n_parts = n_parts;
+    const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
+    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess ||
+        hipMalloc(&c->build.d_count, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        free_db(c); index_abort(c);
+        return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
+    }
     hipStream_t st = c->streams[0];
-    const uint32_t nblk = (uint32_t)((n + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
-    Scope tmp;
-    unsigned long long *d_blk = nullptr; uint64_t *d_boff = nullptr;
-    TMP_MALLOC(tmp, d_blk, (size_t)nblk * 8);
-    TMP_MALLOC(tmp, d_boff, (size_t)nblk * 8);
-    hipLaunchKernelGGL(mc::mz::mz_blocksum_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_v, n, d_blk);
-    HIPCHK(hipGetLastError());
-    std::vector<unsigned long long> blk(nblk);
-    HIPCHK(hipMemcpyAsync(blk.data(), d_blk, (size_t)nblk * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint64_t> boff(nblk);
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < nblk; i++) { boff[i] = acc; acc += blk[i]; }
-    if (acc >= 0xFFFFFFFFull) return fail(MC_EINVAL, "minimizer index: more than 2^32 extra lines");
-    HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(mc::mz::mz_scan_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_v, n, d_boff, d_out);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
-    *total = acc;
+    HIPCHK(hipMemsetAsync(c->build.d_count, 0, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4, st));
+    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, st));
+    c->build.open = true; c->build.pass = 0; c->build.n_keys_total = n_keys_total;
     return MC_OK;
 }
 
+// one chunk, device arrays in the context's key width
 template <bool WIDE>
-int mz_build_passes(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels, uint64_t nb,
-                    uint64_t shard_begin, const uint64_t *d_koff, uint32_t nblk, uint32_t n_lines,
-                    uint32_t *d_count, uint32_t *d_cursor, uint32_t *d_extra, uint32_t *d_ebase, uint64_t *n_extra)
+int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels, uint64_t n_keys,
+                    uint64_t b0, uint64_t b1)
 {
     typedef typename mc::KeyOf<WIDE>::type key_t;
-    hipStream_t st = c->streams[0];
-    hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
-                       static_cast<const key_t *>(d_keys), d_labels, nb, shard_begin, c->htsize, d_koff, c->k, c->mz_m,
-                       n_lines, d_count, d_cursor, (const uint32_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr);
-    HIPCHK(hipGetLastError());
-    const int g = (int)std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, 16384);
-    Scope tmp;
-    uint32_t *d_max = nullptr, max_extra = 0;
-    TMP_MALLOC(tmp, d_max, 4);
-    HIPCHK(hipMemsetAsync(d_max, 0, 4, st));
-    hipLaunchKernelGGL(mc::mz::mz_extra_count_kernel, dim3(g), dim3(256), 0, st, d_count, n_lines, d_extra, d_max);
-    HIPCHK(hipGetLastError());
-    int rc = scan_u32_device(c, d_extra, n_lines, d_ebase, n_extra);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(&max_extra, d_max, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (max_extra > 0xFFFFu)              // one minimizer shared by > 786 000 k-mers: use the direct table
-        return fail(MC_ENOMEM, "minimizer index: a line chain exceeds 65535 extra lines");
-    const size_t ebytes = (size_t)(*n_extra ? *n_extra : 1) * mc::mz::MZ_LINE;
-    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess) return fail(MC_ENOMEM, "minimizer index: extra lines");
-    HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
-    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(g), dim3(256), 0, st, d_extra, d_ebase, n_lines, c->d_mz_lines);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
-                       static_cast<const key_t *>(d_keys), d_labels, nb, shard_begin, c->htsize, d_koff, c->k, c->mz_m,
-                       n_lines, d_count, d_cursor, d_ebase, c->d_mz_lines, c->d_mz_extra);
-    HIPCHK(hipGetLastError());
-    if (*n_extra && !getenv("MC_MZ_NO_REGROUP")) {      // whole minimizer groups first in overflowing lines
-        const int gr = (int)std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, (uint64_t)c->n_cu * 16);
-        hipLaunchKernelGGL(mc::mz::mz_regroup_kernel, dim3(gr), dim3(256), 0, st, d_count, d_ebase, n_lines, c->k,
-                           c->mz_m, c->d_mz_lines, c->d_mz_extra);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipStreamSynchronize(st));
-    return MC_OK;
-}
-
-// Build the minimizer index (mc_minimizer.hpp) from the same raw arrays.
-int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
-                uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
-{
-    const uint64_t nb = shard_end - shard_begin;
+    const uint64_t nb = b1 - b0;
     hipStream_t st = c->streams[0];
     const uint32_t nblk = (uint32_t)((nb + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
     Scope tmp;
@@ -240,43 +151,147 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     uint64_t *d_koff = nullptr;
     TMP_MALLOC(tmp, d_koff, (size_t)nblk * 8);
     HIPCHK(hipMemcpyAsync(d_koff, koff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+    if (c->build.pass == 0)
+        hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
+                           c->mz_n_lines, c->mz_line0, c->mz_n_local, c->build.d_count,
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, 0u);
+    else
+        hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
+                           c->mz_n_lines, c->mz_line0, c->mz_n_local, c->build.d_count,
+                           c->d_mz_lines, c->d_mz_extra, c->d_mz_side, c->mz_n_side);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));       // the temporaries go out of scope
+    c->build.fed[c->build.pass] += n_keys;
+    c->build.bucket_lo = std::min(c->build.bucket_lo, b0);
+    c->build.bucket_hi = std::max(c->build.bucket_hi, b1);
+    return MC_OK;
+}
 
-    free_db(c);
-    double per_line = 6.0;
-    if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
-    const uint64_t want = (uint64_t)((double)n_keys / per_line) + 1024;
-    if (want >= 0xFFFFFFF0ull) return fail(MC_EINVAL, "minimizer index: too many lines");
-    const uint32_t n_lines = (uint32_t)want;
-    c->mz_n_lines = n_lines;
-    c->mz_m = mc::mz::mmer_len(c->k);
-    uint32_t *d_count = nullptr, *d_cursor = nullptr, *d_extra = nullptr, *d_ebase = nullptr;
-    const size_t lbytes = (size_t)n_lines * mc::mz::MZ_LINE;
-    auto grab = [&](uint32_t *&ptr) {
-        if (hipMalloc(&ptr, (size_t)n_lines * 4) != hipSuccess) return false;
-        tmp.add(ptr);
-        return true;
-    };
-    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess || !grab(d_count) || !grab(d_cursor) || !grab(d_extra) || !grab(d_ebase)) {
-        (void)hipGetLastError();
-        return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
-    }
-    HIPCHK(hipMemsetAsync(d_count, 0, (size_t)n_lines * 4, st));
-    HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)n_lines * 4, st));
-    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, st));
-    uint64_t n_extra = 0;
-    int rc = c->wide ? mz_build_passes<true>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra)
-                     : mz_build_passes<false>(c, d_sz, d_keys, d_labels, nb, shard_begin, d_koff, nblk, n_lines, d_count, d_cursor, d_extra, d_ebase, &n_extra);
+int convert_keys(mc_ctx *c, void *d_raw, int key_bytes, uint64_t n, bool raw_owned, void **out, bool *out_owned);
+
+int index_add_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int key_bytes, const uint16_t *d_labels,
+                     uint64_t n_keys, uint64_t b0, uint64_t b1)
+{
+    if (!c->build.open) return fail(MC_ESTATE, "mc_index_add before mc_index_begin");
+    if (b0 >= b1 || b1 > c->htsize) return fail(MC_EINVAL, "bad bucket range of the chunk");
+    Scope tmp;
+    void *keys = nullptr; bool owned = false;
+    int rc = convert_keys(c, const_cast<void *>(d_keys), key_bytes, n_keys, false, &keys, &owned);
     if (rc) return rc;
-    c->info.htsize = c->htsize;
-    c->info.shard_begin = shard_begin; c->info.shard_end = shard_end;
-    c->info.n_keys = n_keys;
-    c->info.n_overflow_buckets = n_extra;            // extra lines
-    c->info.n_overflow_keys = 0;
-    c->info.line_bytes = mc::mz::MZ_LINE;
-    c->info.line_capacity = mc::mz::MZ_CAP;
-    c->info.device_bytes = lbytes + n_extra * mc::mz::MZ_LINE;
+    if (owned) tmp.add(keys);
+    return c->wide ? index_add_typed<true>(c, d_sz, keys, d_labels, n_keys, b0, b1)
+                   : index_add_typed<false>(c, d_sz, keys, d_labels, n_keys, b0, b1);
+}
+
+int index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,
+                   uint64_t n_keys, uint64_t b0, uint64_t b1)
+{
+    if (!c->build.open) return fail(MC_ESTATE, "mc_index_add before mc_index_begin");
+    if (b0 >= b1 || b1 > c->htsize) return fail(MC_EINVAL, "bad bucket range of the chunk");
+    const uint64_t nb = b1 - b0;
+    Scope tmp;
+    uint8_t *d_sz = nullptr; void *d_raw = nullptr; uint16_t *d_labels = nullptr;
+    TMP_MALLOC(tmp, d_sz, nb);
+    TMP_MALLOC(tmp, d_raw, (n_keys ? n_keys : 1) * (size_t)key_bytes);
+    TMP_MALLOC(tmp, d_labels, (n_keys ? n_keys : 1) * 2);
+    HIPCHK(hipMemcpy(d_sz, sz, nb, hipMemcpyHostToDevice));
+    if (n_keys) {
+        HIPCHK(hipMemcpy(d_raw, keys, n_keys * (size_t)key_bytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_labels, labels, n_keys * 2, hipMemcpyHostToDevice));
+    }
+    return index_add_device(c, d_sz, d_raw, key_bytes, d_labels, n_keys, b0, b1);
+}
+
+// between the passes: sizes known -> headers, extra lines, side table
+int index_next_pass(mc_ctx *c)
+{
+    if (!c->build.open || c->build.pass != 0) return fail(MC_ESTATE, "mc_index_next_pass out of order");
+    hipStream_t st = c->streams[0];
+    const uint64_t n = c->mz_n_local;
+    const uint32_t nblk = (uint32_t)std::max<uint64_t>(1, (n + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    Scope tmp;
+    uint32_t *d_blk = nullptr; unsigned long long *d_tot = nullptr; uint64_t *d_boff = nullptr;
+    TMP_MALLOC(tmp, d_blk, (size_t)nblk * 4);
+    TMP_MALLOC(tmp, d_tot, 3 * 8);
+    TMP_MALLOC(tmp, d_boff, (size_t)nblk * 8);
+    HIPCHK(hipMemsetAsync(d_tot, 0, 3 * 8, st));
+    hipLaunchKernelGGL(mc::mz::mz_extras_blocksum_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_blk, d_tot);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> blk(nblk);
+    unsigned long long tot[3];
+    HIPCHK(hipMemcpyAsync(blk.data(), d_blk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> boff(nblk);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < nblk; i++) { boff[i] = acc; acc += blk[i]; }
+    if (acc >= 0xFFFFFFFFull) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: more than 2^32 extra lines"); }
+    c->build.n_extra = acc; c->build.n_spilled = tot[0]; c->build.n_over = tot[1]; c->build.longest = (uint32_t)tot[2];
+    // side table: spilled k-mers at half load, in lines addressed by the k-mer
+    const uint64_t want_side = tot[0] ? tot[0] / (mc::mz::MZ_CAP / 2) + 64 : 0;
+    if (want_side >= 0xFFFFFFF0ull) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: side table too large"); }
+    c->mz_n_side = (uint32_t)want_side;
+    const size_t ebytes = (size_t)(acc ? acc : 1) * mc::mz::MZ_LINE;
+    const size_t sbytes = (size_t)(want_side ? want_side : 1) * mc::mz::MZ_LINE;
+    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess || hipMalloc(&c->d_mz_side, sbytes) != hipSuccess) {
+        (void)hipGetLastError();
+        free_db(c); index_abort(c);
+        return fail(MC_ENOMEM, "minimizer index: not enough HBM for the extra lines");
+    }
+    HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
+    HIPCHK(hipMemsetAsync(c->d_mz_side, 0xFF, sbytes, st));
+    HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_boff, c->d_mz_lines);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->build.d_count, 0, (size_t)(n ? n : 1) * 4, st));      // the counters become the cursors
+    HIPCHK(hipStreamSynchronize(st));
+    c->build.pass = 1;
+    return MC_OK;
+}
+
+int index_end(mc_ctx *c)
+{
+    if (!c->build.open || c->build.pass != 1) return fail(MC_ESTATE, "mc_index_end out of order");
+    if (c->build.fed[0] != c->build.fed[1]) { free_db(c); index_abort(c); return fail(MC_EINVAL, "the two passes were fed different k-mer counts"); }
+    hipStream_t st = c->streams[0];
+    if (c->build.n_over && !getenv("MC_MZ_NO_REGROUP")) {      // whole minimizer groups first in overflowing lines
+        const int gr = (int)std::min<uint64_t>(((uint64_t)c->mz_n_local + 255) / 256, (uint64_t)c->n_cu * 16);
+        hipLaunchKernelGGL(mc::mz::mz_regroup_kernel, dim3(gr), dim3(256), 0, st, c->build.d_count, c->mz_n_local, c->k,
+                           c->mz_m, c->d_mz_lines, c->d_mz_extra);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    mc_db_info &I = c->info;
+    I.htsize = c->htsize;
+    I.shard_begin = c->build.bucket_lo == ~0ull ? 0 : c->build.bucket_lo;
+    I.shard_end = c->build.bucket_hi ? c->build.bucket_hi : c->htsize;
+    I.n_keys = c->build.fed[0];
+    I.n_overflow_buckets = c->build.n_extra;            // extra lines
+    I.n_overflow_keys = c->build.n_spilled;
+    I.line_bytes = mc::mz::MZ_LINE;
+    I.line_capacity = mc::mz::MZ_CAP;
+    I.device_bytes = ((uint64_t)c->mz_n_local + c->build.n_extra + c->mz_n_side) * mc::mz::MZ_LINE;
+    I.index_kind = MC_INDEX_MINIMIZER;
+    I.n_lines = c->mz_n_lines; I.line_begin = c->mz_line0; I.line_end = c->mz_line0 + c->mz_n_local;
+    I.n_extra_lines = c->build.n_extra; I.n_side_lines = c->mz_n_side;
+    I.n_lines_overflowing = c->build.n_over; I.n_spilled_keys = c->build.n_spilled; I.largest_line = c->build.longest;
+    {   // k-mers this part owns = the sum of its line counters (fed[] counts what streamed past)
+        Scope tmp;
+        unsigned long long *d_sum = nullptr, sum = 0;
+        TMP_MALLOC(tmp, d_sum, 8);
+        HIPCHK(hipMemsetAsync(d_sum, 0, 8, st));
+        const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)c->mz_n_local + 255) / 256, (uint64_t)c->n_cu * 8));
+        hipLaunchKernelGGL(mc::mz::mz_sum_u32_kernel, dim3(g), dim3(256), 0, st, c->build.d_count, (uint64_t)c->mz_n_local, d_sum);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&sum, d_sum, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        I.n_keys_owned = sum;
+    }
+    index_abort(c);         // releases the counters
     int occ = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::mz::mz_query_kernel<false>, mc::BLOCK_THREADS, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::mz::mz_query_kernel<mc::mz::MZ_ALL>, mc::BLOCK_THREADS, 0));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
     if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
@@ -285,18 +300,32 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
     return MC_OK;
 }
 
+// whole (shard of a) table resident on the device as raw arrays: one chunk per pass
+int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
+                uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
+{
+    int rc = index_begin(c, n_keys, 0, 1);
+    if (rc) return rc;
+    const int kb = c->wide ? 8 : 4;
+    rc = index_add_device(c, d_sz, d_keys, kb, d_labels, n_keys, shard_begin, shard_end);
+    if (rc == MC_OK) rc = index_next_pass(c);
+    if (rc == MC_OK) rc = index_add_device(c, d_sz, d_keys, kb, d_labels, n_keys, shard_begin, shard_end);
+    if (rc == MC_OK) rc = index_end(c);
+    if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; }
+    return rc;
+}
+
 // Build the bucket lines from raw arrays resident on the device; d_keys holds u32
 // quotients, or u64 when the context is in wide-key mode.
 int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
-             uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
+             uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end, bool fallback = false)
 {
-    // the minimizer index needs a minimizer space (canonical m-mers) well above the number of lines
-    const uint32_t mz_m = mc::mz::mmer_len(c->k);
-    const bool mz_ok = c->k >= 16 && mz_m >= 6 && (mz_m >= 20 || (1ull << (2 * mz_m - 1)) >= 4 * (n_keys / 6 + 1024));
-    if (c->index_mode == 1 && mz_ok) {
+    if (!fallback && c->index_mode == 1 && mz_eligible(c, n_keys)) {
         const int rcm = relayout_mz(c, d_sz, d_keys, d_labels, n_keys, shard_begin, shard_end);
         if (rcm != MC_ENOMEM) return rcm;
-        free_db(c);                      // not enough HBM for the minimizer lines: direct table
+        // not enough HBM for the minimizer lines: the direct table (about 3x slower to query) -- said aloud
+        fprintf(stderr, "libmcclark: %s; falling back to the bucket-line table\n", g_err.c_str());
+        fallback = true;
     }
     const uint64_t nb = shard_end - shard_begin;
     hipStream_t st = c->streams[0];
@@ -370,6 +399,11 @@ int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t 
     if (rc != MC_OK) return rc;
     HIPCHK(hipStreamSynchronize(st));
 
+    c->info = mc_db_info{};
+    c->info.index_kind = MC_INDEX_BUCKET_LINES;
+    c->info.index_fallback = fallback ? 1u : 0u;
+    c->info.n_parts = 1;
+    c->info.n_keys_owned = n_keys;
     c->info.htsize = c->htsize;
     c->info.shard_begin = shard_begin;
     c->info.shard_end = shard_end;
@@ -435,16 +469,9 @@ int norm_shard(mc_ctx *c, uint64_t &sb, uint64_t &se)
     return MC_OK;
 }
 
-bool pread_all(int fd, void *dst, size_t n, uint64_t off)
-{
-    char *p = (char *)dst;
-    while (n) {
-        ssize_t g = pread(fd, p, n, (off_t)off);
-        if (g <= 0) return false;
-        p += g; off += (uint64_t)g; n -= (size_t)g;
-    }
-    return true;
-}
+} // namespace
+
+namespace mcint {
 
 int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads,
                  uint64_t n_con, uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st)
@@ -463,15 +490,19 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     const dim3 g(grid), b(mc::BLOCK_THREADS);
     if (c->d_mz_lines) {
         mc::mz::MzArgs m{};
-        m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra; m.n_lines = c->mz_n_lines; m.m = c->mz_m;
+        m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra; m.side = c->d_mz_side;
+        m.n_lines = c->mz_n_lines; m.line0 = c->mz_line0; m.n_local = c->mz_n_local; m.n_side = c->mz_n_side;
+        m.m = c->mz_m;
         // canonical k-mers are below 4^k: the floating-point remainder needs k-mer / HTSIZE < 2^32
         const bool fp_ok = c->htsize > 1024 && c->htsize < (1ull << 32) &&
                            (c->k < 32 ? ((unsigned __int128)1 << (2 * c->k)) <= ((unsigned __int128)c->htsize << 32) : false);
         m.inv_htsize = fp_ok ? 1.0 / (double)c->htsize : 0.0;
-        if (c->info.shard_begin != 0 || c->info.shard_end != c->htsize)
-            hipLaunchKernelGGL(mc::mz::mz_query_kernel<true>, g, b, 0, st, m);
+        if (c->info.n_parts > 1)
+            hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_LINES>, g, b, 0, st, m);
+        else if (c->info.shard_begin != 0 || c->info.shard_end != c->htsize)
+            hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_BUCKETS>, g, b, 0, st, m);
         else
-            hipLaunchKernelGGL(mc::mz::mz_query_kernel<false>, g, b, 0, st, m);
+            hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_ALL>, g, b, 0, st, m);
     } else if (!c->wide) {
         if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, false>), g, b, 0, st, a);
         else                          hipLaunchKernelGGL((mc::query_kernel<128, false>), g, b, 0, st, a);
@@ -485,7 +516,134 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     return MC_OK;
 }
 
-} // namespace
+int launch_merge_result(mc_ctx *c, const uint16_t *const *d_srcs, uint32_t n_srcs, uint64_t n_reads,
+                        uint16_t *d_out_rows, uint16_t *d_final, hipStream_t st)
+{
+    if (n_srcs < 1 || n_srcs > (uint32_t)mc::MERGE_MAX_SRCS) return fail(MC_EINVAL, "1 to 16 row sources");
+    if (n_reads == 0) return MC_OK;
+    mc::RowSrcs S{};
+    for (uint32_t i = 0; i < n_srcs; i++) { if (!d_srcs[i]) return fail(MC_EINVAL, "NULL row source"); S.p[i] = d_srcs[i]; }
+    S.n = n_srcs;
+    const uint32_t row_len = 2 * c->maxhits + 2;
+    const uint32_t g = (uint32_t)((n_reads + 255) / 256);
+    hipLaunchKernelGGL(mc::merge_result_kernel, dim3(g), dim3(256), 0, st, S, row_len, n_reads, d_out_rows, d_final);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+// ---- database files, streamed in bucket order ------------------------------------
+namespace {
+bool pread_all(int fd, void *dst, size_t n, uint64_t off)
+{
+    char *p = (char *)dst;
+    while (n) {
+        ssize_t g = pread(fd, p, n, (off_t)off);
+        if (g <= 0) return false;
+        p += g; off += (uint64_t)g; n -= (size_t)g;
+    }
+    return true;
+}
+}
+
+DbFileStream::~DbFileStream()
+{
+    if (fs >= 0) close(fs);
+    if (fk >= 0) close(fk);
+    if (fl >= 0) close(fl);
+}
+
+int DbFileStream::open(const char *base_path, int kb, uint32_t smp, uint64_t ht, uint64_t b, uint64_t e)
+{
+    base = base_path; key_bytes = kb; sampling = smp; htsize = ht; sb = b; se = e;
+    fs = ::open((base + ".sz").c_str(), O_RDONLY);
+    fk = ::open((base + ".ky").c_str(), O_RDONLY);
+    fl = ::open((base + ".lb").c_str(), O_RDONLY);
+    if (fs < 0 || fk < 0 || fl < 0) return fail(MC_EIO, "Failed to open " + base + ".sz/.ky/.lb");
+    // bucket sizes of the whole table (the sampling counter runs over all non-empty
+    // buckets, reference CuClarkDB.cu:503-513)
+    sz.resize(htsize);
+    if (!pread_all(fs, sz.data(), htsize, 0)) return fail(MC_EIO, base + ".sz is shorter than htsize");
+    const bool all = sampling <= 1;
+    if (!all) fsz = sz;
+    uint64_t nonzero = 0;
+    file_k0 = 0; n_keys_kept = 0;
+    for (uint64_t i = 0; i < htsize; i++) {
+        if (sz[i] == 0) continue;
+        nonzero++;
+        const bool kp = all || (nonzero % sampling) == 0;
+        if (i < sb) file_k0 += sz[i];
+        if (!kp) sz[i] = 0;
+        else if (i >= sb && i < se) n_keys_kept += sz[i];
+    }
+    return MC_OK;
+}
+
+int DbFileStream::pass(const ChunkFn &f)
+{
+    const uint64_t CH = 1ull << 24;   // buckets per step
+    const std::vector<uint8_t> &file_sz = fsz.empty() ? sz : fsz;
+    std::vector<uint8_t> kbuf, lbuf;
+    uint64_t fpos = file_k0;
+    for (uint64_t b0 = sb; b0 < se; b0 += CH) {
+        const uint64_t b1 = std::min(se, b0 + CH);
+        uint64_t nfile = 0;
+        for (uint64_t i = b0; i < b1; i++) nfile += file_sz[i];
+        kbuf.resize(nfile * (size_t)key_bytes); lbuf.resize(nfile * 2);
+        if (nfile && (!pread_all(fk, kbuf.data(), kbuf.size(), fpos * (uint64_t)key_bytes) ||
+                      !pread_all(fl, lbuf.data(), lbuf.size(), fpos * 2)))
+            return fail(MC_EIO, base + ".ky/.lb shorter than the bucket sizes say");
+        uint64_t nkeep = nfile;
+        if (!fsz.empty()) {                      // drop the unsampled buckets
+            uint64_t r = 0, w = 0;
+            for (uint64_t i = b0; i < b1; i++) {
+                const uint64_t n = file_sz[i];
+                if (n && sz[i]) {
+                    memmove(kbuf.data() + w * key_bytes, kbuf.data() + r * key_bytes, n * key_bytes);
+                    memmove(lbuf.data() + w * 2, lbuf.data() + r * 2, n * 2);
+                    w += n;
+                }
+                r += n;
+            }
+            nkeep = w;
+        }
+        const int rc = f(sz.data() + b0, (const void *)kbuf.data(), (const uint16_t *)lbuf.data(), nkeep, b0, b1);
+        if (rc != MC_OK) return rc;
+        fpos += nfile;
+    }
+    return MC_OK;
+}
+
+bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode == 1 && mz_eligible(c, n_keys_total); }
+
+int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_parts)
+{
+    int rc = MC_OK;
+    auto abort_all = [&]() { const std::string keep = g_err; for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); free_db(ctxs[i]); index_abort(ctxs[i]); } g_err = keep; };
+    for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
+        rc = set_dev(ctxs[i]);
+        if (rc == MC_OK) rc = index_begin(ctxs[i], F.n_keys_kept, line_parts ? i : 0, line_parts ? n : 1);
+    }
+    for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
+        rc = F.pass([&](const uint8_t *sz, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t b0, uint64_t b1) {
+            for (uint32_t i = 0; i < n; i++) {
+                int r = set_dev(ctxs[i]);
+                if (r == MC_OK) r = index_add_host(ctxs[i], sz, keys, F.key_bytes, labels, nk, b0, b1);
+                if (r != MC_OK) return r;
+            }
+            return (int)MC_OK;
+        });
+        for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
+            rc = set_dev(ctxs[i]);
+            if (rc == MC_OK) rc = pass == 0 ? index_next_pass(ctxs[i]) : index_end(ctxs[i]);
+        }
+    }
+    if (rc != MC_OK) abort_all();
+    return rc;
+}
+
+} // namespace mcint
+
+using mcint::launch_query;
 
 extern "C" {
 
@@ -542,6 +700,7 @@ int mc_close(mc_ctx *c)
     (void)hipDeviceSynchronize();
     mc_free_batches(c);
     free_db(c);
+    index_abort(c);
     if (c->d_over) (void)hipFree(c->d_over);
     for (int i = 0; i < 2; i++) if (c->streams[i]) (void)hipStreamDestroy(c->streams[i]);
     delete c;
@@ -600,80 +759,101 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
     if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
     int rc = set_dev(c); if (rc) return rc;
     rc = norm_shard(c, sb, se); if (rc) return rc;
-    const std::string b(base);
-    int fs = open((b + ".sz").c_str(), O_RDONLY);
-    int fk = open((b + ".ky").c_str(), O_RDONLY);
-    int fl = open((b + ".lb").c_str(), O_RDONLY);
-    auto closeall = [&]() { if (fs >= 0) close(fs); if (fk >= 0) close(fk); if (fl >= 0) close(fl); };
-    if (fs < 0 || fk < 0 || fl < 0) { closeall(); return fail(MC_EIO, "Failed to open " + b + ".sz/.ky/.lb"); }
-
-    // bucket sizes of the whole table (the sampling counter runs over all non-empty
-    // buckets, reference CuClarkDB.cu:503-513)
-    std::vector<uint8_t> sz(c->htsize);
-    if (!pread_all(fs, sz.data(), c->htsize, 0)) { closeall(); return fail(MC_EIO, b + ".sz is shorter than htsize"); }
-    const bool all = sampling <= 1;
-    uint64_t nonzero = 0, file_k0 = 0, kept = 0;
-    std::vector<uint8_t> keep;
-    if (!all) keep.assign(c->htsize, 0);
-    for (uint64_t i = 0; i < c->htsize; i++) {
-        if (sz[i] == 0) continue;
-        nonzero++;
-        const bool kp = all || (nonzero % sampling) == 0;
-        if (!all) keep[i] = kp;
-        if (i < sb) file_k0 += sz[i];
-        else if (i < se && kp) kept += sz[i];
+    mcint::DbFileStream F;
+    rc = F.open(base, key_bytes, sampling, c->htsize, sb, se); if (rc) return rc;
+    bool fallback = false;
+    if (mcint::minimizer_index_possible(c, F.n_keys_kept)) {
+        // two passes over the files in chunks: neither the raw arrays nor a second copy ever sits in HBM
+        rc = mcint::load_streamed(&c, 1, F, false);
+        if (rc != MC_ENOMEM) return rc;
+        fprintf(stderr, "libmcclark: %s; falling back to the bucket-line table\n", g_err.c_str());
+        fallback = true;
     }
-    const uint64_t nb = se - sb;
+    // bucket-line table: the raw arrays of the shard go to the device whole
+    const uint64_t nb = se - sb, kept = F.n_keys_kept;
     Scope tmp;
     uint8_t *d_sz = nullptr; char *d_raw = nullptr; uint16_t *d_labels = nullptr;
     TMP_MALLOC(tmp, d_sz, nb ? nb : 1);
     TMP_MALLOC(tmp, d_raw, (kept ? kept : 1) * (size_t)key_bytes);
     TMP_MALLOC(tmp, d_labels, (kept ? kept : 1) * 2);
-
-    // stream the shard's keys/labels through a staging buffer, dropping unsampled buckets
-    const uint64_t CH = 1ull << 24;   // buckets per step
-    std::vector<uint8_t> kbuf, lbuf;
-    uint64_t fpos = file_k0, dpos = 0;
-    for (uint64_t b0 = sb; b0 < se; b0 += CH) {
-        const uint64_t b1 = std::min(se, b0 + CH);
-        uint64_t nfile = 0;
-        for (uint64_t i = b0; i < b1; i++) nfile += sz[i];
-        kbuf.resize(nfile * (size_t)key_bytes); lbuf.resize(nfile * 2);
-        if (nfile && (!pread_all(fk, kbuf.data(), kbuf.size(), fpos * (uint64_t)key_bytes) ||
-                      !pread_all(fl, lbuf.data(), lbuf.size(), fpos * 2))) {
-            closeall(); return fail(MC_EIO, b + ".ky/.lb shorter than the bucket sizes say");
+    uint64_t dpos = 0;
+    rc = F.pass([&](const uint8_t *, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t, uint64_t) {
+        if (nk) {
+            HIPCHK(hipMemcpy(d_raw + dpos * (size_t)key_bytes, keys, nk * (size_t)key_bytes, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_labels + dpos, labels, nk * 2, hipMemcpyHostToDevice));
         }
-        uint64_t nkeep = nfile;
-        if (!all) {
-            uint64_t r = 0, w = 0;
-            for (uint64_t i = b0; i < b1; i++) {
-                const uint64_t n = sz[i];
-                if (n && keep[i]) {
-                    memmove(kbuf.data() + w * key_bytes, kbuf.data() + r * key_bytes, n * key_bytes);
-                    memmove(lbuf.data() + w * 2, lbuf.data() + r * 2, n * 2);
-                    w += n;
-                } else if (n) {
-                    sz[i] = 0;
-                }
-                r += n;
-            }
-            nkeep = w;
-        }
-        if (nkeep) {
-            HIPCHK(hipMemcpy(d_raw + dpos * (size_t)key_bytes, kbuf.data(), nkeep * (size_t)key_bytes, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_labels + dpos, lbuf.data(), nkeep * 2, hipMemcpyHostToDevice));
-        }
-        fpos += nfile; dpos += nkeep;
-    }
-    closeall();
+        dpos += nk;
+        return (int)MC_OK;
+    });
+    if (rc) return rc;
     if (dpos != kept) return fail(MC_EINVAL, "internal: kept-key count mismatch");
-    HIPCHK(hipMemcpy(d_sz, sz.data() + sb, nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sz, F.sz.data() + sb, nb, hipMemcpyHostToDevice));
     void *d_keys = nullptr; bool owned = false;
     tmp.forget(d_raw);                       // convert_keys takes it over (frees or returns it)
     rc = convert_keys(c, d_raw, key_bytes, kept, true, &d_keys, &owned);
     if (rc != MC_OK) return rc;
     tmp.add(d_keys);
-    return relayout(c, d_sz, d_keys, d_labels, kept, sb, se);
+    return relayout(c, d_sz, d_keys, d_labels, kept, sb, se, fallback);
+}
+
+int mc_load_db_part(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, uint32_t part, uint32_t n_parts)
+{
+    if (!c || !base) return fail(MC_EINVAL, "ctx/base is NULL");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
+    if (n_parts < 1 || part >= n_parts) return fail(MC_EINVAL, "bad part / n_parts");
+    int rc = set_dev(c); if (rc) return rc;
+    mcint::DbFileStream F;
+    rc = F.open(base, key_bytes, sampling, c->htsize, 0, c->htsize); if (rc) return rc;
+    if (!mz_eligible(c, F.n_keys_kept)) return fail(MC_EINVAL, "line-range parts need the minimizer index (k >= 16)");
+    rc = index_begin(c, F.n_keys_kept, part, n_parts);
+    for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
+        rc = F.pass([&](const uint8_t *sz, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t b0, uint64_t b1) {
+            return index_add_host(c, sz, keys, key_bytes, labels, nk, b0, b1);
+        });
+        if (rc == MC_OK) rc = pass == 0 ? index_next_pass(c) : index_end(c);
+    }
+    if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; }
+    return rc;
+}
+
+/* ---- the streamed index build, for callers that produce the table in chunks ---- */
+int mc_index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    int rc = set_dev(c); if (rc) return rc;
+    return index_begin(c, n_keys_total, part, n_parts);
+}
+
+int mc_index_add_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int key_bytes, const uint16_t *d_labels,
+                        uint64_t n_keys, uint64_t bucket_begin, uint64_t bucket_end)
+{
+    if (!c || !d_sz) return fail(MC_EINVAL, "NULL argument");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
+    int rc = set_dev(c); if (rc) return rc;
+    return index_add_device(c, d_sz, d_keys, key_bytes, d_labels, n_keys, bucket_begin, bucket_end);
+}
+
+int mc_index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,
+                      uint64_t n_keys, uint64_t bucket_begin, uint64_t bucket_end)
+{
+    if (!c || !sz) return fail(MC_EINVAL, "NULL argument");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
+    int rc = set_dev(c); if (rc) return rc;
+    return index_add_host(c, sz, keys, key_bytes, labels, n_keys, bucket_begin, bucket_end);
+}
+
+int mc_index_next_pass(mc_ctx *c)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    int rc = set_dev(c); if (rc) return rc;
+    return index_next_pass(c);
+}
+
+int mc_index_end(mc_ctx *c)
+{
+    if (!c) return fail(MC_EINVAL, "ctx is NULL");
+    int rc = set_dev(c); if (rc) return rc;
+    return index_end(c);
 }
 
 int mc_get_db_info(mc_ctx *c, mc_db_info *out)
@@ -853,6 +1033,15 @@ int mc_result_rows_device(mc_ctx *c, const uint16_t *d_rows, uint64_t n_reads, u
                        d_rows, row_len, n_reads, d_final);
     HIPCHK(hipGetLastError());
     return MC_OK;
+}
+
+int mc_merge_result_device(mc_ctx *c, const uint16_t *const *d_srcs, uint32_t n_srcs, uint64_t n_reads,
+                           uint16_t *d_out_rows, uint16_t *d_final, void *stream)
+{
+    if (!c || !d_srcs) return fail(MC_EINVAL, "NULL argument");
+    if (!d_out_rows && !d_final) return fail(MC_EINVAL, "no output selected");
+    int rc = set_dev(c); if (rc) return rc;
+    return mcint::launch_merge_result(c, d_srcs, n_srcs, n_reads, d_out_rows, d_final, (hipStream_t)stream);
 }
 
 } // extern "C"

@@ -588,6 +588,59 @@ static __global__ void merge_rows_kernel(const uint16_t *A, const uint16_t *B, u
     for (uint32_t i = 0; i < row_len; i++) ro[i] = i < 1u + 2u * n ? tmp[i] : (uint16_t)0;
 }
 
+// K-way form of the two kernels around it, for the multi-GPU combine: rows of up to MERGE_MAX_SRCS shards
+// -> merged row (optional) and final row (optional) in one pass, one thread per read.  Same result as
+// folding the sources pairwise through merge_rows_kernel and then result_rows_kernel: the union keeps the
+// maxhits smallest ids, equal ids add (saturating), top-2 by ascending scan with strict '>'
+// (reference CuClarkDB.cu:909-928 merges pairwise along a device tree, then :963-968).
+static constexpr int MERGE_MAX_SRCS = 16;
+struct RowSrcs {
+    const uint16_t *p[MERGE_MAX_SRCS];
+    uint32_t n;
+};
+static __global__ void merge_result_kernel(const RowSrcs S, uint32_t row_len, uint64_t n_reads,
+                                           uint16_t *out_rows, uint16_t *out5)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t maxhits = (row_len - 2u) / 2u;
+    uint32_t idx[MERGE_MAX_SRCS], cnt[MERGE_MAX_SRCS];
+#pragma unroll
+    for (int w = 0; w < MERGE_MAX_SRCS; w++) {
+        idx[w] = 0;
+        cnt[w] = (uint32_t)w < S.n ? S.p[w][r * row_len] : 0u;
+        if (cnt[w] > maxhits) cnt[w] = maxhits;                   // malformed input cannot run off the row
+    }
+    uint16_t best = 0, s_best = 0, ibest = 0, isbest = 0, sum = 0;
+    uint16_t *ro = out_rows ? out_rows + r * row_len : nullptr;
+    uint32_t n = 0;
+    while (n < maxhits) {
+        uint32_t t = 0x10000u;
+#pragma unroll
+        for (int w = 0; w < MERGE_MAX_SRCS; w++)
+            if (idx[w] < cnt[w]) { const uint32_t tw = S.p[w][r * row_len + 1u + 2u * idx[w]]; t = tw < t ? tw : t; }
+        if (t == 0x10000u) break;
+        uint32_t h = 0;
+#pragma unroll
+        for (int w = 0; w < MERGE_MAX_SRCS; w++)
+            if (idx[w] < cnt[w] && S.p[w][r * row_len + 1u + 2u * idx[w]] == t) { h += S.p[w][r * row_len + 2u + 2u * idx[w]]; idx[w]++; }
+        const uint16_t sc = (uint16_t)sat_u16(h);
+        if (ro) { ro[1u + 2u * n] = (uint16_t)t; ro[2u + 2u * n] = sc; }
+        if (sc > best) { s_best = best; isbest = ibest; best = sc; ibest = (uint16_t)(t + 1u); }
+        else if (sc > s_best) { s_best = sc; isbest = (uint16_t)(t + 1u); }
+        sum = (uint16_t)(sum + sc);
+        n++;
+    }
+    if (ro) {
+        ro[0] = (uint16_t)n;
+        for (uint32_t i = 1u + 2u * n; i < row_len; i++) ro[i] = 0;
+    }
+    if (out5) {
+        uint16_t *o = out5 + r * 5;
+        o[0] = sum; o[1] = ibest; o[2] = best; o[3] = isbest; o[4] = s_best;
+    }
+}
+
 // ref CuClarkDB.cu:1361-1411
 static __global__ void result_rows_kernel(const uint16_t *rows, uint32_t row_len, uint64_t n_reads,
                                    uint16_t *out5)

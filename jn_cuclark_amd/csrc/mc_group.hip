@@ -1,0 +1,456 @@
+// mc_group.hip -- several GPUs behind one handle (include/mc_group.h): replicas or shards, the
+// device-to-device row exchange, the k-way merge on the owner.  Replaces the multi-device half of the
+// reference's device manager (src/CuClarkDB.cu:118-215, :516-559, :842-851, :909-928).
+//
+// Stream discipline (shards).  Member m works on its context's stream `batch & 1`: wait until the owners
+// have read the rows of the batch that used this slot before -> H2D -> query kernel (sparse rows of ALL
+// reads) -> event.  Owner j then, on its own stream: wait for every member's event -> pull its read range
+// of their rows (hipMemcpyPeerAsync: xGMI, point to point, every link carries 1/G of the rows once) ->
+// k-way merge + top-2 -> D2H of its range -> event `done[j]`.  Two batches are in flight per device, so
+// the exchange and merge of one overlap the query kernel of the next.
+#include "../../include/mc_group.h"
+#include "mc_internal.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+using mcint::fail;
+
+namespace {
+
+struct GSlot {
+    uint32_t *d_ptr = nullptr;
+    uint16_t *d_con = nullptr;
+    uint16_t *d_rows = nullptr;      // shards: rows of all reads; replicas: rows of the batch (extended)
+    uint16_t *d_recv = nullptr;      // shards: (W-1) x per x row_len, the other members' rows of my read range
+    uint16_t *d_final = nullptr;
+    uint16_t *d_merged = nullptr;    // shards + extended: merged rows of my read range
+    hipEvent_t ev_query = nullptr;
+};
+
+struct GBatch {
+    uint32_t *h_ptr = nullptr;
+    uint16_t *h_con = nullptr;
+    uint16_t *h_final = nullptr;
+    uint16_t *h_rows = nullptr;
+    std::vector<hipEvent_t> done;    // per member
+    bool submitted = false;
+};
+
+} // namespace
+
+struct mc_group {
+    std::vector<mc_ctx *> ctx;
+    uint32_t k = 0, maxhits = 0, num_targets = 0;
+    uint64_t htsize = 0;
+    mc_group_info info{};
+    bool loaded = false;
+    std::vector<GBatch> batches;
+    std::vector<GSlot> slots;        // [member * 2 + slot]
+    uint64_t max_reads = 0, max_con = 0, per = 0;
+    bool want_rows = false;
+    // batches may be submitted in any order (the host packs them on several threads): slots and, for
+    // replicas, members are dealt by SUBMISSION order
+    uint64_t n_submitted = 0;
+    int last_on_slot[2] = {-1, -1};  // shards: the batch whose rows the owners last pulled from this slot
+};
+
+namespace {
+
+uint32_t W(const mc_group *g) { return (uint32_t)g->ctx.size(); }
+
+void range_of(const mc_group *g, uint64_t n_reads, uint32_t j, uint64_t &lo, uint64_t &cnt)
+{
+    const uint64_t per = (n_reads + W(g) - 1) / W(g);
+    lo = std::min<uint64_t>(n_reads, (uint64_t)j * per);
+    cnt = std::min<uint64_t>(n_reads, lo + per) - lo;
+}
+
+int free_batches(mc_group *g)
+{
+    for (uint32_t m = 0; m < W(g); m++) {
+        (void)hipSetDevice(g->ctx[m]->device);
+        (void)hipDeviceSynchronize();
+    }
+    for (auto &b : g->batches) {
+        if (b.h_ptr) (void)hipHostFree(b.h_ptr);
+        if (b.h_con) (void)hipHostFree(b.h_con);
+        if (b.h_final) (void)hipHostFree(b.h_final);
+        if (b.h_rows) (void)hipHostFree(b.h_rows);
+        for (size_t m = 0; m < b.done.size(); m++)
+            if (b.done[m]) { (void)hipSetDevice(g->ctx[m]->device); (void)hipEventDestroy(b.done[m]); }
+    }
+    g->batches.clear();
+    g->n_submitted = 0; g->last_on_slot[0] = g->last_on_slot[1] = -1;
+    for (size_t i = 0; i < g->slots.size(); i++) {
+        GSlot &s = g->slots[i];
+        (void)hipSetDevice(g->ctx[i / 2]->device);
+        if (s.d_ptr) (void)hipFree(s.d_ptr);
+        if (s.d_con) (void)hipFree(s.d_con);
+        if (s.d_rows) (void)hipFree(s.d_rows);
+        if (s.d_recv) (void)hipFree(s.d_recv);
+        if (s.d_final) (void)hipFree(s.d_final);
+        if (s.d_merged) (void)hipFree(s.d_merged);
+        if (s.ev_query) (void)hipEventDestroy(s.ev_query);
+    }
+    g->slots.clear();
+    return MC_OK;
+}
+
+// HBM a full replica of the table needs (the choice between replicas and shards)
+uint64_t bytes_for_table(const mc_ctx *c, uint64_t n_keys, uint64_t nb)
+{
+    if (mcint::minimizer_index_possible(c, n_keys)) {
+        double per_line = 6.0;
+        if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
+        const uint64_t n_lines = (uint64_t)((double)n_keys / per_line) + 1024;
+        return n_lines * 128 + n_lines * 128 / 25 + n_lines * 4 + (3ull << 30);     // lines, ~4 % extra lines, counters, chunk staging
+    }
+    return nb * 128 + n_keys * 14;        // bucket lines (worst case 128 B) next to the raw arrays during the fill
+}
+
+} // namespace
+
+extern "C" {
+
+int mc_group_open(mc_group **out, const int *devices, uint32_t n_devices, uint32_t k, uint64_t htsize,
+                  uint32_t num_targets, uint32_t maxhits)
+{
+    if (!out) return fail(MC_EINVAL, "out is NULL");
+    *out = nullptr;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return fail(MC_ENODEVICE, "no HIP device visible");
+    std::vector<int> devs;
+    const char *env = devices ? nullptr : getenv("MC_GROUP_DEVICES");
+    if (env && *env) {
+        // explicit member list, e.g. 0,0,1 (a device may repeat: the sharded path rehearsed on one card)
+        for (const char *p = env; *p;) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            if (v < 0 || v >= visible) return fail(MC_ENODEVICE, "MC_GROUP_DEVICES names a device that is not visible");
+            devs.push_back((int)v);
+            p = *end ? end + 1 : end;
+        }
+        if (devs.empty()) return fail(MC_EINVAL, "MC_GROUP_DEVICES is not a list of device numbers");
+    } else if (devices) {
+        if (n_devices < 1) return fail(MC_EINVAL, "empty device list");
+        devs.assign(devices, devices + n_devices);
+    } else {
+        const uint32_t n = n_devices ? n_devices : (uint32_t)visible;          // 0 = all (CuClarkDB.cu:146-150)
+        if (n > (uint32_t)visible)
+            return fail(MC_ENODEVICE, std::to_string(n) + " devices requested. Insufficient devices found. Abort.");
+        for (uint32_t i = 0; i < n; i++) devs.push_back((int)i);
+    }
+    if (devs.size() > 16) return fail(MC_EINVAL, "at most 16 members");
+    mc_group *g = new mc_group();
+    g->k = k; g->htsize = htsize; g->num_targets = num_targets; g->maxhits = maxhits;
+    for (int d : devs) {
+        mc_ctx *c = nullptr;
+        const int rc = mc_open(&c, d, k, htsize, num_targets, maxhits);
+        if (rc != MC_OK) { mc_group_close(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    // peer access between every pair of distinct devices (CuClarkDB.cu:201-213); without it
+    // hipMemcpyPeerAsync still works (staged), only slower
+    std::set<int> distinct(devs.begin(), devs.end());
+    bool all_peer = true;
+    for (int a : distinct) {
+        for (int b : distinct) {
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { all_peer = false; continue; }
+            (void)hipSetDevice(a);
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) all_peer = false;
+            (void)hipGetLastError();
+        }
+    }
+    g->info.n_members = (uint32_t)devs.size();
+    g->info.peer_access = all_peer ? 1u : 0u;
+    *out = g;
+    return MC_OK;
+}
+
+int mc_group_close(mc_group *g)
+{
+    if (!g) return MC_OK;
+    free_batches(g);
+    for (mc_ctx *c : g->ctx) mc_close(c);
+    delete g;
+    return MC_OK;
+}
+
+int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t sampling, int mode)
+{
+    if (!g || !base) return fail(MC_EINVAL, "group/base is NULL");
+    if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
+    if (mode < MC_GROUP_AUTO || mode > MC_GROUP_SHARDS) return fail(MC_EINVAL, "bad mode");
+    g->loaded = false;
+    mcint::DbFileStream F;
+    int rc = F.open(base, key_bytes, sampling, g->htsize, 0, g->htsize);
+    if (rc) return rc;
+    const uint32_t n = W(g);
+    mc_ctx *c0 = g->ctx[0];
+    const bool mz = mcint::minimizer_index_possible(c0, F.n_keys_kept);
+
+    // the budget (CuClarkDB.cu:516-559): free HBM of the smallest device, shared by the members on it
+    uint64_t free_min = ~0ull;
+    for (uint32_t m = 0; m < n; m++) {
+        size_t fr = 0, tot = 0;
+        if ((rc = mcint::set_dev(g->ctx[m])) != MC_OK) return rc;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        uint32_t sharing = 0;
+        for (uint32_t o = 0; o < n; o++) sharing += g->ctx[o]->device == g->ctx[m]->device ? 1u : 0u;
+        free_min = std::min<uint64_t>(free_min, fr / sharing);
+    }
+    if (const char *e = getenv("MC_GROUP_HBM_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) free_min = std::min(free_min, v); }
+    const uint64_t need_one = bytes_for_table(c0, F.n_keys_kept, g->htsize);
+    if (mode == MC_GROUP_AUTO) {
+        if (const char *e = getenv("MC_GROUP_MODE")) {
+            if (!strcmp(e, "replicas")) mode = MC_GROUP_REPLICAS;
+            else if (!strcmp(e, "shards")) mode = MC_GROUP_SHARDS;
+        }
+    }
+    if (mode == MC_GROUP_AUTO) mode = (n == 1 || need_one + (4ull << 30) <= free_min) ? MC_GROUP_REPLICAS : MC_GROUP_SHARDS;
+    if (n == 1) mode = MC_GROUP_REPLICAS;
+
+    uint32_t shard_kind = 0;
+    if (mode == MC_GROUP_REPLICAS) {
+        if (mz) rc = mcint::load_streamed(g->ctx.data(), n, F, false);
+        if (!mz || rc == MC_ENOMEM) {
+            for (uint32_t m = 0; m < n; m++) {           // bucket-line tables (or the fallback to them), device by device
+                rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, 0, 0);
+                if (rc != MC_OK) break;
+            }
+        }
+    } else if (mz && !(getenv("MC_GROUP_SHARD") && !strcmp(getenv("MC_GROUP_SHARD"), "buckets"))) {
+        shard_kind = 1;
+        rc = mcint::load_streamed(g->ctx.data(), n, F, true);
+    } else {
+        shard_kind = 2;                                   // the reference's own partition (CuClarkDB.cu:552-559)
+        for (uint32_t m = 0; m < n; m++) {
+            rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, g->htsize * m / n, g->htsize * (m + 1) / n);
+            if (rc != MC_OK) break;
+        }
+    }
+    if (rc == MC_ENOMEM)
+        return fail(MC_ENOMEM, std::string("the database does not fit the ") + std::to_string(n) + " device(s) of the group (" +
+                                   mc_last_error() + "); use more devices (-d)");
+    if (rc != MC_OK) return rc;
+    g->info.mode = (uint32_t)mode;
+    g->info.shard_kind = shard_kind;
+    g->info.n_keys = F.n_keys_kept;
+    g->info.bytes_needed_one = need_one;
+    g->info.bytes_free_min = free_min;
+    g->info.device_bytes_max = 0;
+    for (mc_ctx *c : g->ctx) g->info.device_bytes_max = std::max<uint64_t>(g->info.device_bytes_max, c->info.device_bytes);
+    g->loaded = true;
+    return MC_OK;
+}
+
+int mc_group_get_info(mc_group *g, mc_group_info *out)
+{
+    if (!g || !out) return fail(MC_EINVAL, "NULL argument");
+    *out = g->info;
+    return MC_OK;
+}
+
+int mc_group_member(mc_group *g, uint32_t i, mc_ctx **out)
+{
+    if (!g || !out || i >= W(g)) return fail(MC_EINVAL, "bad member index");
+    *out = g->ctx[i];
+    return MC_OK;
+}
+
+int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, uint64_t max_con, int want_rows)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    if (!g->loaded) return fail(MC_ESTATE, "mc_group_alloc_batches before a database was loaded");
+    if (n_batches < 1 || max_reads < 1) return fail(MC_EINVAL, "n_batches and max_reads must be >= 1");
+    if (max_con > 0xFFFFFFFFull) return fail(MC_EINVAL, "max_containers exceeds the 32-bit offsets of the batch format");
+    free_batches(g);
+    if (max_con < 8) max_con = 8;
+    max_con = (max_con + 7) & ~7ull;
+    const uint32_t n = W(g);
+    const bool shards = g->info.mode == MC_GROUP_SHARDS;
+    g->max_reads = max_reads; g->max_con = max_con; g->want_rows = want_rows != 0;
+    g->per = (max_reads + n - 1) / n;
+    const size_t row_len = 2 * (size_t)g->maxhits + 2;
+    auto oom = [&](const char *what, hipError_t e) {
+        free_batches(g);
+        return fail(MC_ENOMEM, std::string(what) + ": " + hipGetErrorString(e) + " -- use more, smaller batches (-b)");
+    };
+    int rc = mcint::set_dev(g->ctx[0]); if (rc) return rc;
+    g->batches.resize(n_batches);
+    for (auto &b : g->batches) {
+        // portable: every device of the group copies from / into these
+        hipError_t e = hipHostMalloc((void **)&b.h_ptr, (max_reads + 1) * 4, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_con, max_con * 2, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_final, max_reads * MC_FINAL_ROW * 2, hipHostMallocPortable);
+        if (e == hipSuccess && g->want_rows) e = hipHostMalloc((void **)&b.h_rows, max_reads * row_len * 2, hipHostMallocPortable);
+        if (e != hipSuccess) return oom("pinned batch buffers", e);
+        b.done.assign(n, nullptr);
+        for (uint32_t m = 0; m < n; m++) {
+            if ((rc = mcint::set_dev(g->ctx[m])) != MC_OK) { free_batches(g); return rc; }
+            e = hipEventCreateWithFlags(&b.done[m], hipEventDisableTiming);
+            if (e != hipSuccess) return oom("events", e);
+        }
+    }
+    g->slots.resize((size_t)n * 2);
+    for (uint32_t m = 0; m < n; m++) {
+        if ((rc = mcint::set_dev(g->ctx[m])) != MC_OK) { free_batches(g); return rc; }
+        for (int si = 0; si < 2; si++) {
+            GSlot &s = g->slots[(size_t)m * 2 + si];
+            hipError_t e = hipMalloc(&s.d_ptr, (max_reads + 1) * 4);
+            if (e == hipSuccess) e = hipMalloc(&s.d_con, max_con * 2);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_query, hipEventDisableTiming);
+            if (shards) {
+                if (e == hipSuccess) e = hipMalloc(&s.d_rows, max_reads * row_len * 2);
+                if (e == hipSuccess) e = hipMalloc(&s.d_recv, (size_t)(n > 1 ? n - 1 : 1) * g->per * row_len * 2);
+                if (e == hipSuccess) e = hipMalloc(&s.d_final, g->per * MC_FINAL_ROW * 2);
+                if (e == hipSuccess && g->want_rows) e = hipMalloc(&s.d_merged, g->per * row_len * 2);
+            } else {
+                if (e == hipSuccess) e = hipMalloc(&s.d_final, max_reads * MC_FINAL_ROW * 2);
+                if (e == hipSuccess && g->want_rows) e = hipMalloc(&s.d_rows, max_reads * row_len * 2);
+            }
+            if (e != hipSuccess) return oom("device batch buffers", e);
+        }
+    }
+    return MC_OK;
+}
+
+int mc_group_batch_buffers(mc_group *g, uint32_t batch, uint32_t **reads_ptr, uint16_t **containers,
+                           uint16_t **final_rows, uint16_t **sparse_rows)
+{
+    if (!g || batch >= g->batches.size()) return fail(MC_EINVAL, "bad batch index");
+    GBatch &b = g->batches[batch];
+    if (reads_ptr) *reads_ptr = b.h_ptr;
+    if (containers) *containers = b.h_con;
+    if (final_rows) *final_rows = b.h_final;
+    if (sparse_rows) *sparse_rows = b.h_rows;
+    return MC_OK;
+}
+
+int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_con, uint32_t flags)
+{
+    if (!g || batch >= g->batches.size()) return fail(MC_EINVAL, "bad batch index");
+    if (n_reads > g->max_reads || n_con > g->max_con) return fail(MC_EINVAL, "batch larger than allocated");
+    if (!(flags & (MC_F_FINAL | MC_F_ROWS))) return fail(MC_EINVAL, "flags select no output");
+    if ((flags & MC_F_ROWS) && !g->want_rows) return fail(MC_ESTATE, "sparse rows were not allocated");
+    GBatch &b = g->batches[batch];
+    if (n_reads && b.h_ptr[n_reads] != n_con) return fail(MC_EINVAL, "reads_ptr[n_reads] != n_containers");
+    const uint32_t n = W(g);
+    const size_t row_len = 2 * (size_t)g->maxhits + 2;
+    int rc;
+
+    if (g->info.mode != MC_GROUP_SHARDS) {
+        // replicas: the batch goes to one member; its two slots alternate
+        const uint32_t m = (uint32_t)(g->n_submitted % n);
+        const int si = (int)((g->n_submitted / n) & 1u);
+        g->n_submitted++;
+        mc_ctx *c = g->ctx[m];
+        GSlot &s = g->slots[(size_t)m * 2 + si];
+        hipStream_t st = c->streams[si];
+        if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
+        if (n_reads) {
+            HIPCHK(hipMemcpyAsync(s.d_ptr, b.h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+            if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, b.h_con, n_con * 2, hipMemcpyHostToDevice, st));
+            rc = mcint::launch_query(c, s.d_ptr, s.d_con, n_reads, n_con, flags, s.d_final, s.d_rows, st);
+            if (rc) return rc;
+            if (flags & MC_F_FINAL) HIPCHK(hipMemcpyAsync(b.h_final, s.d_final, n_reads * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, st));
+            if (flags & MC_F_ROWS) HIPCHK(hipMemcpyAsync(b.h_rows, s.d_rows, n_reads * row_len * 2, hipMemcpyDeviceToHost, st));
+        }
+        for (uint32_t o = 0; o < n; o++) {                 // every member's event is signalled: wait() needs no mode
+            if ((rc = mcint::set_dev(g->ctx[o])) != MC_OK) return rc;
+            HIPCHK(hipEventRecord(b.done[o], o == m ? st : g->ctx[o]->streams[si]));
+        }
+        b.submitted = true;
+        return MC_OK;
+    }
+
+    // ---- shards ----------------------------------------------------------------------------------
+    const int si = (int)(g->n_submitted++ & 1u);
+    const int prev = g->last_on_slot[si];
+    g->last_on_slot[si] = (int)batch;
+    // every device: (slot free?) -> H2D -> rows of all reads for its share of the table
+    for (uint32_t m = 0; m < n; m++) {
+        mc_ctx *c = g->ctx[m];
+        GSlot &s = g->slots[(size_t)m * 2 + si];
+        hipStream_t st = c->streams[si];
+        if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
+        if (prev >= 0 && prev != (int)batch)                        // the owners pulled from this slot's rows
+            for (uint32_t j = 0; j < n; j++)
+                if (j != m) HIPCHK(hipStreamWaitEvent(st, g->batches[prev].done[j], 0));
+        if (n_reads) {
+            HIPCHK(hipMemcpyAsync(s.d_ptr, b.h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+            if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, b.h_con, n_con * 2, hipMemcpyHostToDevice, st));
+            rc = mcint::launch_query(c, s.d_ptr, s.d_con, n_reads, n_con, MC_F_ROWS, nullptr, s.d_rows, st);
+            if (rc) return rc;
+        }
+        HIPCHK(hipEventRecord(s.ev_query, st));
+    }
+    // every owner: pull its read range from the others, merge, top-2, back to the host
+    for (uint32_t j = 0; j < n; j++) {
+        mc_ctx *c = g->ctx[j];
+        GSlot &s = g->slots[(size_t)j * 2 + si];
+        hipStream_t st = c->streams[si];
+        if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
+        uint64_t lo, cnt;
+        range_of(g, n_reads, j, lo, cnt);
+        if (cnt) {
+            const uint16_t *srcs[mc::MERGE_MAX_SRCS];
+            uint32_t r = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                GSlot &o = g->slots[(size_t)i * 2 + si];
+                if (i == j) { srcs[i] = s.d_rows + lo * row_len; continue; }
+                HIPCHK(hipStreamWaitEvent(st, o.ev_query, 0));
+                uint16_t *dst = s.d_recv + (size_t)r * g->per * row_len;
+                HIPCHK(hipMemcpyPeerAsync(dst, c->device, o.d_rows + lo * row_len, g->ctx[i]->device, cnt * row_len * 2, st));
+                srcs[i] = dst;
+                r++;
+            }
+            rc = mcint::launch_merge_result(c, srcs, n, cnt, (flags & MC_F_ROWS) ? s.d_merged : nullptr,
+                                            (flags & MC_F_FINAL) ? s.d_final : nullptr, st);
+            if (rc) return rc;
+            if (flags & MC_F_FINAL)
+                HIPCHK(hipMemcpyAsync(b.h_final + lo * MC_FINAL_ROW, s.d_final, cnt * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, st));
+            if (flags & MC_F_ROWS)
+                HIPCHK(hipMemcpyAsync(b.h_rows + lo * row_len, s.d_merged, cnt * row_len * 2, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipEventRecord(b.done[j], st));
+    }
+    b.submitted = true;
+    return MC_OK;
+}
+
+int mc_group_wait(mc_group *g, uint32_t batch)
+{
+    if (!g || batch >= g->batches.size()) return fail(MC_EINVAL, "bad batch index");
+    GBatch &b = g->batches[batch];
+    if (!b.submitted) return fail(MC_ESTATE, "batch was never submitted");
+    for (uint32_t m = 0; m < W(g); m++) {
+        int rc = mcint::set_dev(g->ctx[m]); if (rc) return rc;
+        HIPCHK(hipEventSynchronize(b.done[m]));
+    }
+    return MC_OK;
+}
+
+int mc_group_sync(mc_group *g)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    for (mc_ctx *c : g->ctx) { int rc = mc_sync(c); if (rc) return rc; }
+    return MC_OK;
+}
+
+int mc_group_free_batches(mc_group *g)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    return free_batches(g);
+}
+
+} // extern "C"

@@ -1,0 +1,148 @@
+// mc_internal.hpp -- what the translation units of libmcclark.so share: the context, the
+// error channel, scoped device temporaries.  Nothing here is part of the C ABI.
+#pragma once
+
+#include "../../include/mc_api.h"
+#include "mc_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace mcint {
+
+// sets the thread-local message mc_last_error() returns; returns `code`
+int fail(int code, const std::string &msg);
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return mcint::fail(MC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Device temporaries of one API call: released when the call returns, on every path.
+struct Scope {
+    std::vector<void *> ptrs;
+    ~Scope() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    void add(void *p) { ptrs.push_back(p); }
+    void drop(void *p)      // release early (large temporaries), or after ownership moved on
+    {
+        for (auto &q : ptrs) if (q == p && p) { (void)hipFree(p); q = nullptr; }
+    }
+    void forget(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }
+};
+#define TMP_MALLOC(scope, ptr, bytes)                                                   \
+    do {                                                                                \
+        HIPCHK(hipMalloc(&(ptr), (bytes)));                                             \
+        (scope).add(ptr);                                                               \
+    } while (0)
+
+struct Batch {
+    uint32_t *h_ptr = nullptr;
+    uint16_t *h_con = nullptr;
+    uint16_t *h_final = nullptr;
+    uint16_t *h_rows = nullptr;
+    hipEvent_t ev = nullptr;
+    bool submitted = false;
+};
+
+struct Slot {
+    uint32_t *d_ptr = nullptr;
+    uint16_t *d_con = nullptr;
+    uint16_t *d_final = nullptr;
+    uint16_t *d_rows = nullptr;
+};
+
+// a minimizer index under construction (mc_index_begin .. mc_index_end)
+struct IndexBuild {
+    bool open = false;
+    int pass = 0;
+    uint64_t n_keys_total = 0;         // k-mers of the whole table (all parts): sizes the line space
+    uint64_t fed[2] = {0, 0};          // k-mers fed in each pass
+    uint64_t bucket_lo = ~0ull, bucket_hi = 0;
+    uint32_t *d_count = nullptr;       // per owned line: k-mers (pass 0), cursor (pass 1)
+    uint64_t n_extra = 0, n_spilled = 0, n_over = 0;
+    uint32_t longest = 0;
+};
+
+} // namespace mcint
+
+struct mc_ctx {
+    int device = 0;
+    uint32_t k = 0, num_targets = 0, maxhits = 0;
+    uint64_t htsize = 0;
+    mc::DivU64 div{};
+    bool wide = false;          // quotients need 64 bits (reference T64 regime: k = 32)
+    int n_cu = 0;
+
+    hipStream_t streams[2] = {nullptr, nullptr};
+
+    // database
+    bool db_loaded = false;
+    uint8_t *d_lines = nullptr;
+    void *d_ovf_keys = nullptr;
+    uint16_t *d_ovf_labels = nullptr;
+    mc_db_info info{};
+    int grid_blocks = 0;
+
+    // locality-aware index (mc_minimizer.hpp): the default for k >= 16; MC_INDEX=lines
+    // selects the direct bucket-line table instead (also the fallback when the minimizer
+    // lines do not fit in HBM)
+    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
+    uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr, *d_mz_side = nullptr;
+    uint32_t mz_n_lines = 0;           // lines of the whole table (all parts)
+    uint32_t mz_line0 = 0, mz_n_local = 0, mz_n_side = 0, mz_m = 0;
+    mcint::IndexBuild build;
+
+    unsigned long long *d_over = nullptr;
+
+    // batches
+    std::vector<mcint::Batch> batches;
+    mcint::Slot slots[2];
+    uint64_t max_reads = 0, max_con = 0;
+    bool want_rows = false;
+
+    mc_stats stats{};
+};
+
+namespace mcint {
+
+int set_dev(mc_ctx *c);
+// one query launch on `st` (no synchronisation)
+int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads, uint64_t n_con,
+                 uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st);
+// k-way merge of sparse rows (+ top-2) on `st`
+int launch_merge_result(mc_ctx *c, const uint16_t *const *d_srcs, uint32_t n_srcs, uint64_t n_reads,
+                        uint16_t *d_out_rows, uint16_t *d_final, hipStream_t st);
+
+// Streams <base>.sz/.ky/.lb in bucket order: calls chunk(pass, sz, keys, labels, n_keys, b0, b1) for
+// every chunk of buckets [b0, b1) inside [sb, se), twice (pass 0, then between(…), then pass 1), with the
+// -s sampling rule applied (dropped buckets arrive with size 0).  n_keys_kept = k-mers of [sb, se).
+struct DbFileStream {
+    std::string base;
+    int key_bytes = 4;
+    uint32_t sampling = 1;
+    uint64_t htsize = 0, sb = 0, se = 0;
+    uint64_t n_keys_kept = 0;
+    std::vector<uint8_t> sz;           // effective sizes of all buckets (dropped = 0)
+    std::vector<uint8_t> fsz;          // sizes in the files (only when sampling drops buckets)
+    uint64_t file_k0 = 0;              // file position (in k-mers) of bucket sb
+    int fs = -1, fk = -1, fl = -1;
+    ~DbFileStream();
+    int open(const char *base_path, int key_bytes, uint32_t sampling, uint64_t htsize, uint64_t sb, uint64_t se);
+    // one pass over the chunks; f(sz of [b0,b1), keys, labels, n_keys, b0, b1) returns MC_OK to continue
+    typedef std::function<int(const uint8_t *, const void *, const uint16_t *, uint64_t, uint64_t, uint64_t)> ChunkFn;
+    int pass(const ChunkFn &f);
+};
+
+// Build the minimizer index of every context from one stream of the files (each chunk is read once per
+// pass and fed to all contexts).  line_parts: context i owns line range i of n (a line-sharded table);
+// otherwise every context builds the whole [sb, se) range (replicas).  MC_ENOMEM when a context cannot
+// hold its lines.
+int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_parts);
+bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total);
+
+} // namespace mcint

@@ -15,9 +15,13 @@
 //             (orientation-free: x and rc(x) have the same set of canonical m-mers)
 //   line(c) = mulhi(mix32(K(c)), n_lines)
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
-//             12 labels (u16), dword30 = extra lines (16 bits) | Bloom word over their k-mers
-//             (16 bits), dword31 = first extra line
-//   extra lines (same shape) hold what does not fit; they are contiguous per line.
+//             12 labels (u16), dword30 = extra lines (bits 0-2) | spill flag (bit 3) | Bloom word
+//             over the k-mers that are not in the first line (high 16 bits), dword31 = first extra line
+//   extra lines (same shape, at most MZ_EMAX per line, contiguous) hold what does not fit;
+//   what does not fit there either (one minimizer shared by thousands of k-mers: a conserved
+//   m-mer in many genomes) is SPILLED into a side table of the same lines addressed by a hash of
+//   the k-mer itself, so that one crowded minimizer costs a bounded number of line reads and never
+//   costs the rest of the table its index.
 //
 // Lookup is exact: the stored key is the whole canonical k-mer.
 //
@@ -32,6 +36,11 @@ namespace mz {
 
 static constexpr int MZ_LINE = 128;
 static constexpr int MZ_CAP = 12;
+static constexpr int MZ_EMAX = 3;                                        // extra lines chained to a primary line
+static constexpr uint32_t MZ_CHAIN_CAP = (uint32_t)MZ_CAP * (1 + MZ_EMAX);   // k-mers a line keeps (first + extra lines)
+static constexpr uint32_t MZ_HDR_EXTRA = 7u;                             // dword 30: number of extra lines
+static constexpr uint32_t MZ_HDR_SPILL = 8u;                             // dword 30: k-mers of this line live in the side table
+static constexpr uint64_t MZ_EMPTY = ~0ull;
 #ifndef MC_MZ_MAXW
 #define MC_MZ_MAXW 11
 #endif
@@ -129,8 +138,8 @@ __device__ __forceinline__ uint32_t line_of(uint64_t K, uint32_t n_lines)
     return __umulhi(h, n_lines);
 }
 
-// A line's header (dword 30) = number of extra lines (low 16 bits) | a 16-bit Bloom word over the
-// k-mers that live in those extra lines, two bits per k-mer (an overflowing line spills 1-3 k-mers as
+// A line's header (dword 30) = number of extra lines (bits 0-2) | spill flag (bit 3) | a 16-bit Bloom
+// word (high half) over the k-mers that live in those extra lines or in the side table, two bits per k-mer (an overflowing line spills 1-3 k-mers as
 // a rule: 2-5 % false positives instead of 6-17 % with one bit).  A k-mer that is not in the first line
 // follows the chain only if both its bits are set, so nearly every miss ends at the first line.
 __device__ __forceinline__ uint32_t extra_mask(uint64_t c)
@@ -142,14 +151,44 @@ __device__ __forceinline__ uint32_t extra_mask(uint64_t c)
 // ---------------------------------------------------------------------------
 // index build from the raw bucket arrays (sizes u8, quotients, labels)
 // ---------------------------------------------------------------------------
-// PASS 0: count k-mers per line.  PASS 1: place them.
+// PASS 0: count k-mers per line.  PASS 1: place them.  The table arrives in bucket-order CHUNKS
+// (sizes, quotients, labels of buckets [bucket0, bucket0 + n_buckets)), each chunk once per pass, so
+// neither the raw arrays of the whole table nor the file have to be resident next to the lines.
+// A context may own only the lines [line0, line0 + n_local) of the n_lines_total the whole table
+// is spread over (a line-range shard): k-mers of other lines are skipped.
+
+// side table (k-mers beyond a line's chain): lines of the same shape addressed by the k-mer
+__device__ __forceinline__ uint32_t side_line_of(uint64_t c, uint32_t n_side)
+{
+    const uint32_t h = ((uint32_t)(c >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)c * 0x9E3779B1u);
+    return __umulhi(h ^ (h >> 15), n_side);
+}
+
+// open addressing at line granularity: slots of a line fill front to back (a slot is claimed
+// only after its predecessors were seen taken, and nothing is ever removed), so "line full" is
+// "last slot taken" and a lookup may stop at the first line that is not full.
+__device__ __forceinline__ void side_insert(uint8_t *side, uint32_t n_side, uint64_t c, uint16_t label)
+{
+    uint32_t l = side_line_of(c, n_side);
+    for (uint32_t tries = 0; tries < n_side; tries++) {
+        unsigned long long *keys = reinterpret_cast<unsigned long long *>(side + (uint64_t)l * MZ_LINE);
+        for (int e = 0; e < MZ_CAP; e++) {
+            if (keys[e] != MZ_EMPTY) continue;
+            if (atomicCAS(&keys[e], (unsigned long long)MZ_EMPTY, (unsigned long long)c) == MZ_EMPTY) {
+                reinterpret_cast<uint16_t *>(side + (uint64_t)l * MZ_LINE + 8 * MZ_CAP)[e] = label;
+                return;
+            }
+        }
+        l = l + 1u == n_side ? 0u : l + 1u;
+    }
+}
+
 template <int PASS, bool WIDE>
 __global__ __launch_bounds__(RL_THREADS)
 void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, const uint16_t *labels,
                      uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const uint64_t *blk_key_off,
-                     uint32_t k, uint32_t m, uint32_t n_lines,
-                     uint32_t *count, uint32_t *cursor, const uint32_t *extra_base,
-                     uint8_t *lines, uint8_t *extra_lines)
+                     uint32_t k, uint32_t m, uint32_t n_lines_total, uint32_t line0, uint32_t n_local,
+                     uint32_t *count, uint8_t *lines, uint8_t *extra_lines, uint8_t *side, uint32_t n_side)
 {
     __shared__ uint32_t s_a[RL_THREADS / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
@@ -163,50 +202,89 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
         if (b >= n_buckets) break;
         for (uint32_t j = 0; j < cnt[i]; j++) {
             const uint64_t c = (uint64_t)keys[koff + j] * htsize + (bucket0 + b);     // the canonical k-mer
-            const uint32_t l = line_of(kmer_min_key(c, k, m), n_lines);
-            if (PASS == 0) {
-                atomicAdd(&count[l], 1u);
-            } else {
-                const uint32_t slot = atomicAdd(&cursor[l], 1u);
-                uint8_t *base;
-                uint32_t pos;
-                if (slot < (uint32_t)MZ_CAP) { base = lines + (uint64_t)l * MZ_LINE; pos = slot; }
-                else {
-                    const uint32_t e = slot - MZ_CAP;
-                    base = extra_lines + ((uint64_t)extra_base[l] + e / MZ_CAP) * MZ_LINE;
-                    pos = e % MZ_CAP;
-                    atomicOr(reinterpret_cast<uint32_t *>(lines + (uint64_t)l * MZ_LINE) + 30, extra_mask(c));
+            const uint32_t l = line_of(kmer_min_key(c, k, m), n_lines_total) - line0;
+            if (l >= n_local) continue;                                               // another shard's line
+            const uint32_t slot = atomicAdd(&count[l], 1u);       // PASS 1: the counters were reset; they end equal to PASS 0's
+            if (PASS == 1) {
+                uint8_t *first = lines + (uint64_t)l * MZ_LINE;
+                if (slot < (uint32_t)MZ_CAP) {
+                    reinterpret_cast<uint64_t *>(first)[slot] = c;
+                    reinterpret_cast<uint16_t *>(first + 8 * MZ_CAP)[slot] = labels[koff + j];
+                } else {
+                    atomicOr(reinterpret_cast<uint32_t *>(first) + 30, extra_mask(c));
+                    if (slot < MZ_CHAIN_CAP) {
+                        const uint32_t e = slot - MZ_CAP;
+                        uint8_t *base = extra_lines + ((uint64_t)reinterpret_cast<const uint32_t *>(first)[31] + e / MZ_CAP) * MZ_LINE;
+                        reinterpret_cast<uint64_t *>(base)[e % MZ_CAP] = c;
+                        reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[e % MZ_CAP] = labels[koff + j];
+                    } else {
+                        side_insert(side, n_side, c, labels[koff + j]);
+                    }
                 }
-                reinterpret_cast<uint64_t *>(base)[pos] = c;
-                reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[pos] = labels[koff + j];
             }
         }
         koff += cnt[i];
     }
 }
 
-// number of extra lines per line (for the scan) and, later, the headers
-__global__ void mz_extra_count_kernel(const uint32_t *count, uint32_t n_lines, uint32_t *extra, uint32_t *max_extra)
+// after PASS 0: extra lines and spilled k-mers of a line with `c` k-mers
+__host__ __device__ __forceinline__ uint32_t extras_of(uint32_t c)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint32_t mx = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
-        const uint32_t c = count[i];
-        const uint32_t ex = c > (uint32_t)MZ_CAP ? (c - MZ_CAP + MZ_CAP - 1) / MZ_CAP : 0u;
-        extra[i] = ex;
-        mx = ex > mx ? ex : mx;
+    if (c <= (uint32_t)MZ_CAP) return 0u;
+    const uint32_t ex = (c - 1u) / (uint32_t)MZ_CAP;          // ceil((c - CAP) / CAP)
+    return ex > (uint32_t)MZ_EMAX ? (uint32_t)MZ_EMAX : ex;
+}
+__host__ __device__ __forceinline__ uint32_t spilled_of(uint32_t c) { return c > MZ_CHAIN_CAP ? c - MZ_CHAIN_CAP : 0u; }
+
+// per workgroup of RL_BUCKETS lines: extra lines, spilled k-mers, overflowing lines; overall: largest line
+static __global__ __launch_bounds__(RL_THREADS)
+void mz_extras_blocksum_kernel(const uint32_t *count, uint64_t n, uint32_t *blk_extra, unsigned long long *totals)
+{
+    __shared__ uint32_t s_a[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    uint32_t ex = 0, mx = 0;
+    unsigned long long sp = 0, ov = 0;
+    for (int i = 0; i < RL_PER_THREAD; i++) {
+        const uint32_t c = (b0 + i < n) ? count[b0 + i] : 0u;
+        ex += extras_of(c); sp += spilled_of(c); ov += c > (uint32_t)MZ_CAP ? 1u : 0u;
+        mx = c > mx ? c : mx;
     }
-    if (mx) atomicMax(max_extra, mx);
+    uint32_t te;
+    block_exclusive_scan(ex, s_a, te);
+    if (threadIdx.x == 0) blk_extra[blockIdx.x] = te;
+    for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); ov += __shfl_xor(ov, o, 64); const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+    if ((threadIdx.x & 63) == 0) {
+        if (sp) atomicAdd(&totals[0], sp);
+        if (ov) atomicAdd(&totals[1], ov);
+        atomicMax(&totals[2], (unsigned long long)mx);
+    }
 }
 
-// runs BEFORE the placing pass, which ORs the Bloom bits into dword 30
-__global__ void mz_header_kernel(const uint32_t *extra, const uint32_t *extra_base, uint32_t n_lines, uint8_t *lines)
+static __global__ void mz_sum_u32_kernel(const uint32_t *v, uint64_t n, unsigned long long *out)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
-        uint32_t *hdr = reinterpret_cast<uint32_t *>(lines + i * MZ_LINE) + 30;
-        hdr[0] = extra[i];                  // <= 0xFFFF, checked by the host
-        hdr[1] = extra_base[i];
+    unsigned long long s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += v[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// headers: dword 30 = extra lines | spill flag (the placing pass ORs the Bloom bits in), dword 31 = first extra line
+static __global__ __launch_bounds__(RL_THREADS)
+void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_extra_off, uint8_t *lines)
+{
+    __shared__ uint32_t s_a[RL_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
+    uint32_t c[RL_PER_THREAD], ex = 0;
+    for (int i = 0; i < RL_PER_THREAD; i++) { c[i] = (b0 + i < n) ? count[b0 + i] : 0u; ex += extras_of(c[i]); }
+    uint32_t tot;
+    uint64_t o = blk_extra_off[blockIdx.x] + block_exclusive_scan(ex, s_a, tot);
+    for (int i = 0; i < RL_PER_THREAD; i++) {
+        if (b0 + i >= n) break;
+        uint32_t *hdr = reinterpret_cast<uint32_t *>(lines + (b0 + i) * MZ_LINE) + 30;
+        hdr[0] = extras_of(c[i]) | (spilled_of(c[i]) ? MZ_HDR_SPILL : 0u);
+        hdr[1] = (uint32_t)o;
+        o += extras_of(c[i]);
     }
 }
 
@@ -215,12 +293,13 @@ __global__ void mz_header_kernel(const uint32_t *extra, const uint32_t *extra_ba
 // consecutive k-mers) between the first line and its extra lines, so a read crossing that region pays
 // the dependent extra-line fetch for every such run.  Here the chain is rewritten with whole groups
 // first: entries sorted by (size of their minimizer group, descending; minimizer key; k-mer).  One
-// WAVE per overflowing line, one lane per k-mer (chains of more than 64 k-mers stay as placed): group
-// size and rank are counted against every other entry by broadcast, so nothing is sorted in memory.
-// The result no longer depends on the order the atomics happened to run in.
-static constexpr int MZ_REGROUP_MAX = 64;
+// WAVE per overflowing line, one lane per k-mer of its chain (at most MZ_CHAIN_CAP = 48; spilled k-mers
+// stay in the side table): group size and rank are counted against every other entry by broadcast, so
+// nothing is sorted in memory.  Without spills the result no longer depends on the order the atomics
+// happened to run in (with spills, WHICH k-mers spilled does; every lookup finds them either way).
+static_assert(MZ_CHAIN_CAP <= 64, "one lane per chain entry");
 __global__ __launch_bounds__(256)
-void mz_regroup_kernel(const uint32_t *count, const uint32_t *extra_base, uint32_t n_lines, uint32_t k, uint32_t m,
+void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint32_t m,
                        uint8_t *lines, uint8_t *extra_lines)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -229,14 +308,15 @@ void mz_regroup_kernel(const uint32_t *count, const uint32_t *extra_base, uint32
     for (uint64_t base = wave * 64u; base < n_lines; base += n_waves * 64u) {
         const uint64_t mine = base + lane;
         const uint32_t n_mine = mine < n_lines ? count[mine] : 0u;
-        uint64_t todo = __ballot(n_mine > (uint32_t)MZ_CAP && n_mine <= (uint32_t)MZ_REGROUP_MAX);
+        uint64_t todo = __ballot(n_mine > (uint32_t)MZ_CAP);
         while (todo) {
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
             todo &= todo - 1u;
             const uint64_t i = base + l;
-            const uint32_t n = lane_bcast(n_mine, l);
+            const uint32_t n_all = lane_bcast(n_mine, l);
+            const uint32_t n = n_all < MZ_CHAIN_CAP ? n_all : MZ_CHAIN_CAP;
             uint8_t *first = lines + i * MZ_LINE;
-            uint8_t *more = extra_lines + (uint64_t)extra_base[i] * MZ_LINE;
+            uint8_t *more = extra_lines + (uint64_t)reinterpret_cast<const uint32_t *>(first)[31] * MZ_LINE;
             auto slot_line = [&](uint32_t e) -> uint8_t * { return e < (uint32_t)MZ_CAP ? first : more + (uint64_t)(e / MZ_CAP - 1u) * MZ_LINE; };
             const bool have = lane < n;
             uint64_t key = ~0ull, mk = ~0ull;
@@ -268,36 +348,11 @@ void mz_regroup_kernel(const uint32_t *count, const uint32_t *extra_base, uint32
             for (int o = 32; o > 0; o >>= 1) bloom |= (uint32_t)__shfl_xor((int)bloom, o, 64);
             if (lane == 0) {
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
-                hdr[0] = (hdr[0] & 0xFFFFu) | bloom;            // extra_mask() sits in the high half
+                // extra_mask() sits in the high half; a line with spilled k-mers keeps their bits as well
+                hdr[0] = (n_all > MZ_CHAIN_CAP ? hdr[0] : (hdr[0] & 0xFFFFu)) | bloom;
             }
         }
     }
-}
-
-// exclusive scan of u32 -> u32 (per-workgroup sums scanned on the host)
-static __global__ __launch_bounds__(RL_THREADS)
-void mz_blocksum_kernel(const uint32_t *v, uint64_t n, unsigned long long *blk)
-{
-    __shared__ unsigned long long s[RL_THREADS / 64];
-    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
-    unsigned long long sum = 0;
-    for (int i = 0; i < RL_PER_THREAD; i++) if (b0 + i < n) sum += v[b0 + i];
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < RL_THREADS / 64; w++) t += s[w]; blk[blockIdx.x] = t; }
-}
-
-static __global__ __launch_bounds__(RL_THREADS)
-void mz_scan_kernel(const uint32_t *v, uint64_t n, const uint64_t *blk_off, uint32_t *out)
-{
-    __shared__ uint32_t s_a[RL_THREADS / 64];
-    const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
-    uint32_t c[RL_PER_THREAD], sum = 0;
-    for (int i = 0; i < RL_PER_THREAD; i++) { c[i] = (b0 + i < n) ? v[b0 + i] : 0u; sum += c[i]; }
-    uint32_t tot;
-    uint64_t o = blk_off[blockIdx.x] + block_exclusive_scan(sum, s_a, tot);
-    for (int i = 0; i < RL_PER_THREAD; i++) { if (b0 + i < n) out[b0 + i] = (uint32_t)o; o += c[i]; }
 }
 
 // ---------------------------------------------------------------------------
@@ -305,12 +360,21 @@ void mz_scan_kernel(const uint32_t *v, uint64_t n, const uint64_t *blk_off, uint
 // ---------------------------------------------------------------------------
 struct MzArgs {
     QueryArgs q;               // reads, outputs, shard range, div, k, maxhits, flags (lines unused)
-    const uint8_t *lines;      // n_lines primary lines
+    const uint8_t *lines;      // the primary lines this context owns
     const uint8_t *extra;      // extra lines
-    uint32_t n_lines;
+    const uint8_t *side;       // side table (spilled k-mers), n_side lines
+    uint32_t n_lines;          // lines the whole table is spread over (all shards)
+    uint32_t line0, n_local;   // this context owns lines [line0, line0 + n_local)
+    uint32_t n_side;
     uint32_t m;
-    double inv_htsize;         // 1/HTSIZE when the shard filter may use rem_u64_fp, else 0
+    double inv_htsize;         // 1/HTSIZE when the bucket-range filter may use rem_u64_fp, else 0
 };
+
+// which k-mers a context answers for
+enum { MZ_ALL = 0,             // the whole table
+       MZ_BUCKETS = 1,         // k-mers of a bucket range [shard_begin, shard_end) of the reference's hash
+                               // (CuClarkDB.cu:552-559, :1212-1214): every shard fetches nearly every line
+       MZ_LINES = 2 };         // k-mers of a LINE range: a shard fetches, matches and scores 1/G of the runs
 
 // One lane against one 128-byte line parked in LDS.  All key loads are issued before the
 // first compare (twelve dependent LDS round trips otherwise); the compares are one
@@ -355,12 +419,13 @@ static constexpr int MZ_LDS_LINES = MZ_LDS_RUNLINE + MZ_RUNS * 4;
 static constexpr int MZ_LDS_KEYS_BYTES = (64 * MZ_NS + MZ_MAXW + 3) * 8;
 static constexpr int MZ_LDS_WAVE = MZ_LDS_LINES + (MZ_RUNS * MZ_LSTRIDE > MZ_LDS_KEYS_BYTES ? MZ_RUNS * MZ_LSTRIDE : MZ_LDS_KEYS_BYTES);
 static_assert(MZ_LDS_LINES % 16 == 0 && MZ_LDS_WAVE % 16 == 0, "16-byte aligned LDS regions");
-// SHARDED: apply the bucket-range filter of a shard (a separate instantiation keeps the
-// divider and the range out of the unsharded kernel's scalar registers).
-template <bool SHARDED>
+// SHARD: MZ_ALL / MZ_BUCKETS / MZ_LINES (separate instantiations keep the divider and the ranges
+// out of the unsharded kernel's scalar registers).
+template <int SHARD>
 __global__ __launch_bounds__(BLOCK_THREADS, MC_MZ_MIN_WAVES)
 void mz_query_kernel(const MzArgs A)
 {
+    constexpr bool SHARDED = SHARD == MZ_BUCKETS;      // per-k-mer filter; MZ_LINES filters whole runs
     const QueryArgs &a = A.q;
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[WAVES_PER_BLOCK][MZ_LDS_WAVE];
 
@@ -554,10 +619,20 @@ void mz_query_kernel(const MzArgs A)
                         const uint64_t K0 = key_min(v[0], mid), K1 = key_min(mid, v[MZ_MAXW]);
                         line[0] = inpart[0] ? line_of(K0, A.n_lines) : 0xFFFFFFFFu;
                         line[1] = inpart[1] ? line_of(K1, A.n_lines) : 0xFFFFFFFFu;
+                        if constexpr (SHARD == MZ_LINES) {
+                            // local line index; k-mers of lines this context does not own drop out here,
+                            // and only owned runs are numbered (fetched, matched, scored)
+#pragma unroll
+                            for (int s = 0; s < MZ_NS; s++) {
+                                line[s] -= A.line0;
+                                active[s] = inpart[s] && line[s] < A.n_local;
+                            }
+                        }
                         // second line of the lane before (DPP wave_shr:1); nothing before lane 0
                         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)line[1], 0x138, 0xf, 0xf, false);
                         leader[0] = inpart[0] && line[0] != prev;
                         leader[1] = inpart[1] && line[1] != line[0];
+                        if constexpr (SHARD == MZ_LINES) { leader[0] = leader[0] && active[0]; leader[1] = leader[1] && active[1]; }
                         const uint64_t b0 = __ballot(leader[0]), b1 = __ballot(leader[1]);
                         // leaders in lower lanes (v_mbcnt) = index of this lane's first run
                         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
@@ -628,9 +703,14 @@ void mz_query_kernel(const MzArgs A)
                                 // rare: lines beyond the first (Bloom bits are set only where extra lines exist)
                                 const uint32_t xm = extra_mask(c[s]);
                                 if (!hit[s] && (hdr & xm) == xm) {
-                                    const uint32_t extra = hdr & 0xFFFFu;
-                                    for (uint32_t e = 0; e < extra && !hit[s]; e++) {
-                                        const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
+                                    const uint32_t extra = hdr & MZ_HDR_EXTRA;
+                                    // the chain, then (spill flag) the side table: lines addressed by the k-mer,
+                                    // probed until one that is not full
+                                    uint32_t sl = side_line_of(c[s], A.n_side);
+                                    for (uint32_t e = 0; !hit[s]; e++) {
+                                        const bool in_chain = e < extra;
+                                        if (!in_chain && !(hdr & MZ_HDR_SPILL)) break;
+                                        const uint8_t *X = in_chain ? A.extra + ((uint64_t)eb + e) * MZ_LINE : A.side + (uint64_t)sl * MZ_LINE;
                                         u32x4 xv[MZ_CAP / 2];
 #pragma unroll
                                         for (int t = 0; t < MZ_CAP / 2; t++) xv[t] = reinterpret_cast<const u32x4 *>(X)[t];
@@ -641,6 +721,11 @@ void mz_query_kernel(const MzArgs A)
                                             if (key == c[s]) at = t;
                                         }
                                         if (at >= 0) { hit[s] = true; lab[s] = reinterpret_cast<const uint16_t *>(X + 8 * MZ_CAP)[at]; }
+                                        if (!in_chain) {
+                                            const uint64_t last = (uint64_t)xv[MZ_CAP / 2 - 1][2] | ((uint64_t)xv[MZ_CAP / 2 - 1][3] << 32);
+                                            if (last == MZ_EMPTY || e >= extra + A.n_side) break;      // a line with room ends the probe
+                                            sl = sl + 1u == A.n_side ? 0u : sl + 1u;
+                                        }
                                     }
                                 }
                             }

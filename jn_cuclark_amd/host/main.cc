@@ -8,12 +8,13 @@
 // Output: <result>.csv with the reference's columns and number formatting
 // (src/CuCLARK_hh.hh:1945-2122).  GPU work: include/mc_api.h only.
 //
+// -d N (0 or absent = all devices, as the reference, src/CuClarkDB.cu:146-150) goes to mc_group
+// (include/mc_group.h): N replicas when the table fits one GPU, N shards with a device-to-device
+// exchange of the per-read rows when it does not -- the reference always shards (:552-559).
 // Differences from the reference, all outside the per-read results:
-//   * -d N runs N replicas (whole table on every GPU, batches round-robin) instead of
-//     sharding a table that does not fit one Jetson; the sharded multi-GPU path is the
-//     process-per-GPU driver (jn_cuclark_amd/dist.py).
 //   * --tsk (.ht dumps) and spectrum-form targets are not implemented.
 #include "../../include/mc_api.h"
+#include "../../include/mc_group.h"
 #include "common.hpp"
 #include "dbbuild.hpp"
 #include "reads.hpp"
@@ -82,7 +83,7 @@ struct Classifier {
     Targets T;
     std::string folder, dbbase;
     int key_bytes = 4;
-    std::vector<mc_ctx *> ctx;
+    mc_group *grp = nullptr;
     bool paired = false;
     size_t n_objects = 0;
 
@@ -91,12 +92,9 @@ struct Classifier {
         int n = 0;
         if (mc_device_count(&n) != MC_OK || n < 1) die("No HIP devices found. Abort.");
         if ((size_t)n < opt.devices) die(std::to_string(opt.devices) + " devices requested. Insufficient devices found. Abort.");
-        const size_t use = opt.devices ? opt.devices : 1;
-        for (size_t d = 0; d < use; d++) {
-            mc_ctx *c = nullptr;
-            mc_check(mc_open(&c, (int)d, (uint32_t)opt.k, HTSIZE, (uint32_t)(T.names.size() - 1), MAXHITS), "mc_open");
-            ctx.push_back(c);
-        }
+        // (MC_GROUP_DEVICES=0,0,1 in the environment overrides the member list inside the library)
+        mc_check(mc_group_open(&grp, nullptr, (uint32_t)opt.devices, (uint32_t)opt.k, HTSIZE, (uint32_t)(T.names.size() - 1), MAXHITS),
+                 "mc_group_open");
     }
 
     // the database is built on the CPU when its files are missing (reference
@@ -121,16 +119,24 @@ struct Classifier {
     void load()
     {
         if (opt.verbose) std::cerr << "Loading database [" << dbbase << ".*] (s=" << opt.sfactor << ")..." << std::endl;
-        for (auto *c : ctx) {
-            const int rc = mc_load_db(c, dbbase.c_str(), key_bytes, opt.sfactor, 0, 0);
-            if (rc == MC_EIO) die("Failed to find the database.", -1);
-            mc_check(rc, "mc_load_db");
-        }
+        const int rc = mc_group_load_db(grp, dbbase.c_str(), key_bytes, opt.sfactor, MC_GROUP_AUTO);
+        if (rc == MC_EIO) die("Failed to find the database.", -1);
+        mc_check(rc, "mc_group_load_db");
+        mc_group_info gi;
+        mc_group_get_info(grp, &gi);
         if (opt.verbose) {
+            mc_ctx *c0 = nullptr;
             mc_db_info info;
-            mc_get_db_info(ctx[0], &info);
-            std::cerr << "Total DB size in HBM:\t" << info.device_bytes / 1000000 / 1000.0 << " GB (" << info.n_keys
-                      << " k-mers, " << info.line_bytes << "-byte bucket lines)\n";
+            mc_group_member(grp, 0, &c0);
+            mc_get_db_info(c0, &info);
+            std::cerr << "Devices: " << gi.n_members << " ("
+                      << (gi.mode == MC_GROUP_SHARDS ? (gi.shard_kind == 1 ? "shards by minimizer line range" : "shards by bucket range")
+                                                     : "replicas")
+                      << ", peer access " << (gi.peer_access ? "yes" : "no") << ")\n";
+            std::cerr << "Total DB size in HBM:\t" << gi.device_bytes_max / 1000000 / 1000.0 << " GB per device (" << gi.n_keys
+                      << " k-mers, " << (info.index_kind == MC_INDEX_MINIMIZER ? "minimizer index" : "bucket-line table")
+                      << (info.index_fallback ? " [fallback: the minimizer index did not fit]" : "") << ", " << info.line_bytes
+                      << "-byte lines)\n";
             std::cerr << "DB loaded.\n";
         } else {
             std::cerr << "CuCLARK initialized.\n";
@@ -187,13 +193,7 @@ struct Classifier {
         }
         if (max_con > 0xFFFFFFFFull) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).", -1);
 
-        // batches are dealt round-robin to the devices; per device they are numbered 0..
-        const size_t ndev = ctx.size();
-        std::vector<uint32_t> per_dev(ndev, 0);
-        std::vector<std::pair<size_t, uint32_t>> where(nbatch);
-        for (size_t b = 0; b < nbatch; b++) { where[b] = {b % ndev, per_dev[b % ndev]++}; }
-        for (size_t d = 0; d < ndev; d++)
-            if (per_dev[d]) mc_check(mc_alloc_batches(ctx[d], per_dev[d], max_reads, max_con, opt.ext ? 1 : 0), "mc_alloc_batches");
+        mc_check(mc_group_alloc_batches(grp, (uint32_t)nbatch, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
 
         const uint32_t flags = MC_F_FINAL | (opt.ext ? MC_F_ROWS : 0);
         std::vector<size_t> ncon(nbatch, 0);
@@ -203,19 +203,19 @@ struct Classifier {
 #endif
         for (long b = 0; b < (long)nbatch; b++) {
             uint32_t *ptr; uint16_t *con;
-            mc_check(mc_batch_buffers(ctx[where[b].first], where[b].second, &ptr, &con, nullptr, nullptr), "mc_batch_buffers");
+            mc_check(mc_group_batch_buffers(grp, (uint32_t)b, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
             ncon[b] = pack_reads(map, R, first[b], first[b + 1], (unsigned)opt.k, ptr, con);
 #ifdef _OPENMP
 #pragma omp critical(submit)
 #endif
             {
-                mc_check(mc_submit(ctx[where[b].first], where[b].second, first[b + 1] - first[b], ncon[b], flags), "mc_submit");
+                mc_check(mc_group_submit(grp, (uint32_t)b, first[b + 1] - first[b], ncon[b], flags), "mc_group_submit");
             }
         }
         if (dump) {
             for (size_t b = 0; b < nbatch; b++) {
                 uint32_t *ptr; uint16_t *con;
-                mc_batch_buffers(ctx[where[b].first], where[b].second, &ptr, &con, nullptr, nullptr);
+                mc_group_batch_buffers(grp, (uint32_t)b, &ptr, &con, nullptr, nullptr);
                 const uint64_t n = first[b + 1] - first[b], c = ncon[b];
                 std::fwrite(&n, 8, 1, dump); std::fwrite(&c, 8, 1, dump);
                 std::fwrite(ptr, 4, n + 1, dump); std::fwrite(con, 2, c, dump);
@@ -238,9 +238,9 @@ struct Classifier {
         std::vector<std::string> slice(nfmt);
         std::vector<long> s_min(nfmt), s_max(nfmt), s_sum(nfmt);
         for (size_t b = 0; b < nbatch; b++) {
-            mc_check(mc_wait(ctx[where[b].first], where[b].second), "mc_wait");
+            mc_check(mc_group_wait(grp, (uint32_t)b), "mc_group_wait");
             uint16_t *fin, *rows;
-            mc_batch_buffers(ctx[where[b].first], where[b].second, nullptr, nullptr, &fin, &rows);
+            mc_group_batch_buffers(grp, (uint32_t)b, nullptr, nullptr, &fin, &rows);
             const size_t r0 = first[b], nr = first[b + 1] - first[b];
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static, 1) num_threads(nfmt)
@@ -312,7 +312,7 @@ struct Classifier {
         if (opt.ext && n_objects)
             std::cerr << "MIN targets: " << nz_min << ", MAX targets: " << nz_max << ", AVG targets: "
                       << (float)nz_sum / n_objects << "\n";
-        for (size_t d = 0; d < ndev; d++) if (per_dev[d]) mc_free_batches(ctx[d]);
+        mc_group_free_batches(grp);
 
         gettimeofday(&t1, nullptr);
         const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
@@ -422,6 +422,6 @@ int main(int argc, char **argv)
     C.open_devices();
     C.load();
     C.run();
-    for (auto *c : C.ctx) mc_close(c);
+    mc_group_close(C.grp);
     return 0;
 }

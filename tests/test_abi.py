@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "mc_api.h")).read()
+def _declared_symbols(header="mc_api.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mc_[a-z_0-9]+)\s*\(", txt)))
 
@@ -27,9 +27,10 @@ def test_library_exports_every_declared_symbol():
         import __graft_entry__
         __graft_entry__.build()
     lib = ctypes.CDLL(_lib.library_path())
-    for name in _declared_symbols():
+    for name in _declared_symbols() + _declared_symbols("mc_group.h"):
         assert hasattr(lib, name), name
-    assert _lib.load_library().mc_api_version() == 1
+    assert len(_declared_symbols("mc_group.h")) == 11
+    assert _lib.load_library().mc_api_version() == 2
 
 
 def test_builder_symbols_exported():

@@ -363,3 +363,63 @@ def test_fast_g_format_matches_printf(tmp_path):
     r = subprocess.run([exe, "2000", "1000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("checked ")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("members,env,expect", [
+    ("0,0", {"MC_GROUP_MODE": "shards"}, "shards by minimizer line range"),
+    ("0,0,0", {"MC_GROUP_HBM_BYTES": "100000000"}, "shards by minimizer line range"),      # "does not fit": AUTO picks shards
+    ("0,0,0", {"MC_GROUP_MODE": "shards", "MC_GROUP_SHARD": "buckets"}, "shards by bucket range"),
+    ("0,0", {"MC_GROUP_MODE": "shards", "MC_INDEX": "lines"}, "shards by bucket range"),
+    ("0,0,0", {}, "replicas"),
+])
+@pytest.mark.parametrize("extended", [False, True])
+def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members, env, expect, extended):
+    """-d N through mc_group (include/mc_group.h), rehearsed with N contexts on the one card of the test box
+    (MC_GROUP_DEVICES): a table that "does not fit" is cut into line-range shards (bucket ranges as in the
+    reference, CuClarkDB.cu:552-559, when asked for or when the minimizer index is not in use), every shard
+    sees every batch (:842-851), rows are exchanged device-to-device by read range and merged by the owner
+    (:909-928 is the reference's tree).  The CSV must be byte-identical to the one-device run -- with
+    several batches in flight, submitted out of order by four packer threads."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    _build()
+    k, ht = 27, 57777779
+    genomes = synth.toy_genomes(6, 6000, seed=61, shared=400)
+    labels = ["A", "B", "C", "D", "E", "F"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    names, seqs = mixed_fasta(genomes, k, seed=23, n=4000)
+    text = synth.fastq_text(names, seqs)
+    (tmp_path / "reads.fq").write_bytes(text)
+    common = ["-T", targets, "-D", str(dbdir), "-O", str(tmp_path / "reads.fq"), "-n", "4", "-b", "9", "--verbose"]
+    if extended:
+        common.append("--extended")
+    one = subprocess.run([os.path.join(BIN, "cuCLARK-l")] + common + ["-R", str(tmp_path / "one"), "-d", "1"],
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr
+    assert "Devices: 1 (replicas" in one.stderr
+    e = dict(os.environ, MC_GROUP_DEVICES=members, **env)
+    many = subprocess.run([os.path.join(BIN, "cuCLARK-l")] + common + ["-R", str(tmp_path / "many")],
+                          capture_output=True, text=True, timeout=900, env=e)
+    assert many.returncode == 0, many.stderr
+    assert ("Devices: %d (%s" % (len(members.split(",")), expect)) in many.stderr, many.stderr
+    a, b = open(str(tmp_path / "one.csv")).read(), open(str(tmp_path / "many.csv")).read()
+    assert a == b
+    base = str(dbdir / ("db_central_k27_t6_s%d_m0_light_4.tsk" % ht))
+    want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, extended=extended)
+    assert b == want
+    assert sum(ln.split(",")[-3] != "NA" for ln in b.split("\n")[1:-1]) > 1500
+
+
+@pytest.mark.gpu
+def test_more_devices_than_present_is_refused(tmp_path):
+    _build()
+    genomes = synth.toy_genomes(2, 2000, seed=71)
+    targets = _write_targets(tmp_path, genomes, ["A", "B"], n_mask=False)
+    (tmp_path / "db").mkdir()
+    (tmp_path / "r.fa").write_bytes(synth.fasta_text([b"r"], [synth.codes_to_ascii(genomes[0][:150])]))
+    r = _run("cuCLARK-l", ["-T", targets, "-D", str(tmp_path / "db"), "-O", str(tmp_path / "r.fa"), "-R", str(tmp_path / "o"), "-d", "99"])
+    assert r.returncode != 0 and "99 devices requested. Insufficient devices found. Abort." in r.stderr
