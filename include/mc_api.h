@@ -77,9 +77,10 @@ typedef struct mc_db_info {
     uint64_t n_lines;             /* primary lines of the whole table                  */
     uint64_t line_begin, line_end;/* primary lines held here                           */
     uint64_t n_extra_lines;       /* lines chained behind overflowing primary lines    */
-    uint64_t n_side_lines;        /* side table (k-mers of crowded minimizers)         */
+    uint64_t n_lines_crowded;     /* primary lines with more k-mers than one chain holds (48): their k-mers
+                                     are spread over 2^s chains picked by a hash of the k-mer              */
     uint64_t n_lines_overflowing; /* primary lines with more k-mers than slots         */
-    uint64_t n_spilled_keys;      /* k-mers in the side table                          */
+    uint64_t n_spilled_keys;      /* k-mers in the chains of crowded lines             */
     uint32_t largest_line;        /* most k-mers that share one primary line           */
     uint32_t reserved_;
 } mc_db_info;

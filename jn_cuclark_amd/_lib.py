@@ -25,7 +25,7 @@ class McDbInfo(C.Structure):
                 ("index_kind", C.c_uint32), ("index_fallback", C.c_uint32),
                 ("part", C.c_uint32), ("n_parts", C.c_uint32), ("n_keys_owned", C.c_uint64),
                 ("n_lines", C.c_uint64), ("line_begin", C.c_uint64), ("line_end", C.c_uint64),
-                ("n_extra_lines", C.c_uint64), ("n_side_lines", C.c_uint64),
+                ("n_extra_lines", C.c_uint64), ("n_lines_crowded", C.c_uint64),
                 ("n_lines_overflowing", C.c_uint64), ("n_spilled_keys", C.c_uint64),
                 ("largest_line", C.c_uint32), ("reserved_", C.c_uint32)]
 

@@ -53,9 +53,8 @@ void free_db(mc_ctx *c)
     if (c->d_ovf_labels) (void)hipFree(c->d_ovf_labels);
     if (c->d_mz_lines) (void)hipFree(c->d_mz_lines);
     if (c->d_mz_extra) (void)hipFree(c->d_mz_extra);
-    if (c->d_mz_side) (void)hipFree(c->d_mz_side);
     c->d_lines = nullptr; c->d_ovf_keys = nullptr; c->d_ovf_labels = nullptr;
-    c->d_mz_lines = nullptr; c->d_mz_extra = nullptr; c->d_mz_side = nullptr;
+    c->d_mz_lines = nullptr; c->d_mz_extra = nullptr;
     c->db_loaded = false;
 }
 
@@ -84,6 +83,7 @@ int query_occupancy(int &occ)
 void index_abort(mc_ctx *c)
 {
     if (c->build.d_count) (void)hipFree(c->build.d_count);
+    if (c->build.d_failed) (void)hipFree(c->build.d_failed);
     c->build = mcint::IndexBuild();
 }
 
@@ -155,12 +155,12 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
                            static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
                            c->mz_n_lines, c->mz_line0, c->mz_n_local, c->build.d_count,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, 0u);
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, (unsigned int *)nullptr);
     else
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
                            static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
                            c->mz_n_lines, c->mz_line0, c->mz_n_local, c->build.d_count,
-                           c->d_mz_lines, c->d_mz_extra, c->d_mz_side, c->mz_n_side);
+                           c->d_mz_lines, c->d_mz_extra, c->build.d_failed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));       // the temporaries go out of scope
     c->build.fed[c->build.pass] += n_keys;
@@ -214,13 +214,13 @@ int index_next_pass(mc_ctx *c)
     Scope tmp;
     uint32_t *d_blk = nullptr; unsigned long long *d_tot = nullptr; uint64_t *d_boff = nullptr;
     TMP_MALLOC(tmp, d_blk, (size_t)nblk * 4);
-    TMP_MALLOC(tmp, d_tot, 3 * 8);
+    TMP_MALLOC(tmp, d_tot, 4 * 8);
     TMP_MALLOC(tmp, d_boff, (size_t)nblk * 8);
-    HIPCHK(hipMemsetAsync(d_tot, 0, 3 * 8, st));
+    HIPCHK(hipMemsetAsync(d_tot, 0, 4 * 8, st));
     hipLaunchKernelGGL(mc::mz::mz_extras_blocksum_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_blk, d_tot);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> blk(nblk);
-    unsigned long long tot[3];
+    unsigned long long tot[4];
     HIPCHK(hipMemcpyAsync(blk.data(), d_blk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -229,19 +229,15 @@ int index_next_pass(mc_ctx *c)
     for (uint32_t i = 0; i < nblk; i++) { boff[i] = acc; acc += blk[i]; }
     if (acc >= 0xFFFFFFFFull) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: more than 2^32 extra lines"); }
     c->build.n_extra = acc; c->build.n_spilled = tot[0]; c->build.n_over = tot[1]; c->build.longest = (uint32_t)tot[2];
-    // side table: spilled k-mers at half load, in lines addressed by the k-mer
-    const uint64_t want_side = tot[0] ? tot[0] / (mc::mz::MZ_CAP / 2) + 64 : 0;
-    if (want_side >= 0xFFFFFFF0ull) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: side table too large"); }
-    c->mz_n_side = (uint32_t)want_side;
+    c->build.n_crowded = tot[3];
     const size_t ebytes = (size_t)(acc ? acc : 1) * mc::mz::MZ_LINE;
-    const size_t sbytes = (size_t)(want_side ? want_side : 1) * mc::mz::MZ_LINE;
-    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess || hipMalloc(&c->d_mz_side, sbytes) != hipSuccess) {
+    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess || hipMalloc(&c->build.d_failed, 4) != hipSuccess) {
         (void)hipGetLastError();
         free_db(c); index_abort(c);
         return fail(MC_ENOMEM, "minimizer index: not enough HBM for the extra lines");
     }
     HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
-    HIPCHK(hipMemsetAsync(c->d_mz_side, 0xFF, sbytes, st));
+    HIPCHK(hipMemsetAsync(c->build.d_failed, 0, 4, st));
     HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_boff, c->d_mz_lines);
     HIPCHK(hipGetLastError());
@@ -262,7 +258,10 @@ int index_end(mc_ctx *c)
                            c->mz_m, c->d_mz_lines, c->d_mz_extra);
         HIPCHK(hipGetLastError());
     }
+    unsigned int failed = 0;
+    HIPCHK(hipMemcpyAsync(&failed, c->build.d_failed, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (failed) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: a chain of a crowded line overflowed twice"); }
     mc_db_info &I = c->info;
     I.htsize = c->htsize;
     I.shard_begin = c->build.bucket_lo == ~0ull ? 0 : c->build.bucket_lo;
@@ -272,10 +271,10 @@ int index_end(mc_ctx *c)
     I.n_overflow_keys = c->build.n_spilled;
     I.line_bytes = mc::mz::MZ_LINE;
     I.line_capacity = mc::mz::MZ_CAP;
-    I.device_bytes = ((uint64_t)c->mz_n_local + c->build.n_extra + c->mz_n_side) * mc::mz::MZ_LINE;
+    I.device_bytes = ((uint64_t)c->mz_n_local + c->build.n_extra) * mc::mz::MZ_LINE;
     I.index_kind = MC_INDEX_MINIMIZER;
     I.n_lines = c->mz_n_lines; I.line_begin = c->mz_line0; I.line_end = c->mz_line0 + c->mz_n_local;
-    I.n_extra_lines = c->build.n_extra; I.n_side_lines = c->mz_n_side;
+    I.n_extra_lines = c->build.n_extra; I.n_lines_crowded = c->build.n_crowded;
     I.n_lines_overflowing = c->build.n_over; I.n_spilled_keys = c->build.n_spilled; I.largest_line = c->build.longest;
     {   // k-mers this part owns = the sum of its line counters (fed[] counts what streamed past)
         Scope tmp;
@@ -490,19 +489,20 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     const dim3 g(grid), b(mc::BLOCK_THREADS);
     if (c->d_mz_lines) {
         mc::mz::MzArgs m{};
-        m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra; m.side = c->d_mz_side;
-        m.n_lines = c->mz_n_lines; m.line0 = c->mz_line0; m.n_local = c->mz_n_local; m.n_side = c->mz_n_side;
+        m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra;
+        m.n_lines = c->mz_n_lines; m.line0 = c->mz_line0; m.n_local = c->mz_n_local;
         m.m = c->mz_m;
         // canonical k-mers are below 4^k: the floating-point remainder needs k-mer / HTSIZE < 2^32
         const bool fp_ok = c->htsize > 1024 && c->htsize < (1ull << 32) &&
                            (c->k < 32 ? ((unsigned __int128)1 << (2 * c->k)) <= ((unsigned __int128)c->htsize << 32) : false);
         m.inv_htsize = fp_ok ? 1.0 / (double)c->htsize : 0.0;
-        if (c->info.n_parts > 1)
-            hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_LINES>, g, b, 0, st, m);
-        else if (c->info.shard_begin != 0 || c->info.shard_end != c->htsize)
-            hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_BUCKETS>, g, b, 0, st, m);
-        else
-            hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_ALL>, g, b, 0, st, m);
+        const int shard = c->info.n_parts > 1 ? mc::mz::MZ_LINES
+                        : (c->info.shard_begin != 0 || c->info.shard_end != c->htsize) ? mc::mz::MZ_BUCKETS : mc::mz::MZ_ALL;
+        switch (shard) {
+        case mc::mz::MZ_LINES:   hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_LINES>, g, b, 0, st, m); break;
+        case mc::mz::MZ_BUCKETS: hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_BUCKETS>, g, b, 0, st, m); break;
+        default:                 hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_ALL>, g, b, 0, st, m); break;
+        }
     } else if (!c->wide) {
         if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, false>), g, b, 0, st, a);
         else                          hipLaunchKernelGGL((mc::query_kernel<128, false>), g, b, 0, st, a);

@@ -64,7 +64,8 @@ struct IndexBuild {
     uint64_t fed[2] = {0, 0};          // k-mers fed in each pass
     uint64_t bucket_lo = ~0ull, bucket_hi = 0;
     uint32_t *d_count = nullptr;       // per owned line: k-mers (pass 0), cursor (pass 1)
-    uint64_t n_extra = 0, n_spilled = 0, n_over = 0;
+    unsigned int *d_failed = nullptr;  // set by the placing pass when a k-mer found no slot
+    uint64_t n_extra = 0, n_spilled = 0, n_over = 0, n_crowded = 0;
     uint32_t longest = 0;
 };
 
@@ -92,9 +93,9 @@ struct mc_ctx {
     // selects the direct bucket-line table instead (also the fallback when the minimizer
     // lines do not fit in HBM)
     int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
-    uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr, *d_mz_side = nullptr;
+    uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
     uint32_t mz_n_lines = 0;           // lines of the whole table (all parts)
-    uint32_t mz_line0 = 0, mz_n_local = 0, mz_n_side = 0, mz_m = 0;
+    uint32_t mz_line0 = 0, mz_n_local = 0, mz_m = 0;
     mcint::IndexBuild build;
 
     unsigned long long *d_over = nullptr;

@@ -17,11 +17,11 @@
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
 //             12 labels (u16), dword30 = extra lines (bits 0-2) | spill flag (bit 3) | Bloom word
 //             over the k-mers that are not in the first line (high 16 bits), dword31 = first extra line
-//   extra lines (same shape, at most MZ_EMAX per line, contiguous) hold what does not fit;
-//   what does not fit there either (one minimizer shared by thousands of k-mers: a conserved
-//   m-mer in many genomes) is SPILLED into a side table of the same lines addressed by a hash of
-//   the k-mer itself, so that one crowded minimizer costs a bounded number of line reads and never
-//   costs the rest of the table its index.
+//   extra lines (same shape, contiguous per line) hold what does not fit: a chain of at most MZ_EMAX
+//   lines.  A CROWDED line (one minimizer shared by thousands of k-mers: a conserved m-mer in many
+//   genomes) gets 2^s such chains ("segments") and a k-mer's segment is picked by a hash of the k-mer
+//   itself, so that one crowded minimizer costs a lookup at most 2 * MZ_EMAX extra line reads however
+//   many k-mers share it, and never costs the rest of the table its index.
 //
 // Lookup is exact: the stored key is the whole canonical k-mer.
 //
@@ -38,8 +38,12 @@ static constexpr int MZ_LINE = 128;
 static constexpr int MZ_CAP = 12;
 static constexpr int MZ_EMAX = 3;                                        // extra lines chained to a primary line
 static constexpr uint32_t MZ_CHAIN_CAP = (uint32_t)MZ_CAP * (1 + MZ_EMAX);   // k-mers a line keeps (first + extra lines)
-static constexpr uint32_t MZ_HDR_EXTRA = 7u;                             // dword 30: number of extra lines
-static constexpr uint32_t MZ_HDR_SPILL = 8u;                             // dword 30: k-mers of this line live in the side table
+// dword 30 of a primary line: bits 0-2 = extra lines a lookup scans (0..MZ_EMAX; 7 on a crowded line of which
+// some chain was full: a k-mer of it lives in the chain behind), bits 3-7 = s (2^s chains; 0 unless crowded),
+// bits 16-31 = Bloom word
+static constexpr uint32_t MZ_HDR_EXTRA = 7u;
+static constexpr uint32_t MZ_HDR_SEG_SHIFT = 3u, MZ_HDR_SEG_MASK = 31u;
+static constexpr uint32_t MZ_SEG_LOAD = 9u;          // k-mers aimed at per segment of MZ_EMAX * MZ_CAP = 36 slots (P(overflow) ~ 1e-12)
 static constexpr uint64_t MZ_EMPTY = ~0ull;
 #ifndef MC_MZ_MAXW
 #define MC_MZ_MAXW 11
@@ -139,7 +143,7 @@ __device__ __forceinline__ uint32_t line_of(uint64_t K, uint32_t n_lines)
 }
 
 // A line's header (dword 30) = number of extra lines (bits 0-2) | spill flag (bit 3) | a 16-bit Bloom
-// word (high half) over the k-mers that live in those extra lines or in the side table, two bits per k-mer (an overflowing line spills 1-3 k-mers as
+// word (high half) over the k-mers that live in those extra lines, two bits per k-mer (an overflowing line spills 1-3 k-mers as
 // a rule: 2-5 % false positives instead of 6-17 % with one bit).  A k-mer that is not in the first line
 // follows the chain only if both its bits are set, so nearly every miss ends at the first line.
 __device__ __forceinline__ uint32_t extra_mask(uint64_t c)
@@ -157,30 +161,23 @@ __device__ __forceinline__ uint32_t extra_mask(uint64_t c)
 // A context may own only the lines [line0, line0 + n_local) of the n_lines_total the whole table
 // is spread over (a line-range shard): k-mers of other lines are skipped.
 
-// side table (k-mers beyond a line's chain): lines of the same shape addressed by the k-mer
-__device__ __forceinline__ uint32_t side_line_of(uint64_t c, uint32_t n_side)
+// crowded lines: which of the 2^s chains a k-mer belongs to (the top bits of a multiplicative hash; chain 0
+// when s = 0): 5 VALU operations with the header field extraction
+__device__ __forceinline__ uint32_t seg_of(uint64_t c, uint32_t seg_log)
 {
-    const uint32_t h = ((uint32_t)(c >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)c * 0x9E3779B1u);
-    return __umulhi(h ^ (h >> 15), n_side);
+    // both halves go through a multiplication: k-mers that share a minimizer differ in BOTH flanks, and an
+    // xor of the halves lets the flanks cancel
+    const uint32_t h = ((uint32_t)(c >> 32) * 0x85EBCA6Bu + (uint32_t)c) * 0x9E3779B1u;
+    return __umulhi(h, 1u << seg_log);
 }
-
-// open addressing at line granularity: slots of a line fill front to back (a slot is claimed
-// only after its predecessors were seen taken, and nothing is ever removed), so "line full" is
-// "last slot taken" and a lookup may stop at the first line that is not full.
-__device__ __forceinline__ void side_insert(uint8_t *side, uint32_t n_side, uint64_t c, uint16_t label)
+// number of chains (log2) of a line with `c` k-mers: 0 unless it is crowded
+__host__ __device__ __forceinline__ uint32_t seg_log_of(uint32_t c)
 {
-    uint32_t l = side_line_of(c, n_side);
-    for (uint32_t tries = 0; tries < n_side; tries++) {
-        unsigned long long *keys = reinterpret_cast<unsigned long long *>(side + (uint64_t)l * MZ_LINE);
-        for (int e = 0; e < MZ_CAP; e++) {
-            if (keys[e] != MZ_EMPTY) continue;
-            if (atomicCAS(&keys[e], (unsigned long long)MZ_EMPTY, (unsigned long long)c) == MZ_EMPTY) {
-                reinterpret_cast<uint16_t *>(side + (uint64_t)l * MZ_LINE + 8 * MZ_CAP)[e] = label;
-                return;
-            }
-        }
-        l = l + 1u == n_side ? 0u : l + 1u;
-    }
+    if (c <= MZ_CHAIN_CAP) return 0u;
+    const uint32_t want = (c - (uint32_t)MZ_CAP + MZ_SEG_LOAD - 1u) / MZ_SEG_LOAD;      // segments at the aimed load
+    uint32_t s = 1u;
+    while ((1u << s) < want) s++;
+    return s;
 }
 
 template <int PASS, bool WIDE>
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(RL_THREADS)
 void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, const uint16_t *labels,
                      uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const uint64_t *blk_key_off,
                      uint32_t k, uint32_t m, uint32_t n_lines_total, uint32_t line0, uint32_t n_local,
-                     uint32_t *count, uint8_t *lines, uint8_t *extra_lines, uint8_t *side, uint32_t n_side)
+                     uint32_t *count, uint8_t *lines, uint8_t *extra_lines, unsigned int *failed)
 {
     __shared__ uint32_t s_a[RL_THREADS / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
@@ -211,14 +208,32 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
                     reinterpret_cast<uint64_t *>(first)[slot] = c;
                     reinterpret_cast<uint16_t *>(first + 8 * MZ_CAP)[slot] = labels[koff + j];
                 } else {
-                    atomicOr(reinterpret_cast<uint32_t *>(first) + 30, extra_mask(c));
-                    if (slot < MZ_CHAIN_CAP) {
+                    uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
+                    atomicOr(hdr, extra_mask(c));
+                    const uint32_t h0 = *reinterpret_cast<volatile uint32_t *>(hdr);       // low bits: written before this pass
+                    const uint32_t seg_log = (h0 >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK;
+                    uint8_t *chain0 = extra_lines + (uint64_t)hdr[1] * MZ_LINE;
+                    if (seg_log == 0u) {                               // one chain, filled in arrival order
                         const uint32_t e = slot - MZ_CAP;
-                        uint8_t *base = extra_lines + ((uint64_t)reinterpret_cast<const uint32_t *>(first)[31] + e / MZ_CAP) * MZ_LINE;
+                        uint8_t *base = chain0 + (uint64_t)(e / MZ_CAP) * MZ_LINE;
                         reinterpret_cast<uint64_t *>(base)[e % MZ_CAP] = c;
                         reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[e % MZ_CAP] = labels[koff + j];
                     } else {
-                        side_insert(side, n_side, c, labels[koff + j]);
+                        // crowded: the k-mer's own chain, or -- it is full -- the one behind it (one spare chain
+                        // follows the last); slots are claimed with compare-and-swap on the key
+                        const uint32_t seg = seg_of(c, seg_log);
+                        bool placed = false;
+                        for (uint32_t e = 0; e < 2u * MZ_EMAX * MZ_CAP && !placed; e++) {
+                            uint8_t *base = chain0 + ((uint64_t)seg * MZ_EMAX + e / MZ_CAP) * MZ_LINE;
+                            unsigned long long *key = reinterpret_cast<unsigned long long *>(base) + e % MZ_CAP;
+                            if (*key != MZ_EMPTY) continue;
+                            if (atomicCAS(key, (unsigned long long)MZ_EMPTY, (unsigned long long)c) == MZ_EMPTY) {
+                                reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[e % MZ_CAP] = labels[koff + j];
+                                if (e >= MZ_EMAX * MZ_CAP) atomicOr(hdr, 2u * MZ_EMAX);      // 3 | 6 = 7: lookups scan two chains (6 lines; see the query)
+                                placed = true;
+                            }
+                        }
+                        if (!placed) atomicOr(failed, 1u);             // two chains full at a third of the aimed load: ~1e-24
                     }
                 }
             }
@@ -227,36 +242,42 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
     }
 }
 
-// after PASS 0: extra lines and spilled k-mers of a line with `c` k-mers
-__host__ __device__ __forceinline__ uint32_t extras_of(uint32_t c)
+// after PASS 0: extra lines of a line with `c` k-mers (crowded: 2^s chains of MZ_EMAX lines + one spare)
+__host__ __device__ __forceinline__ uint32_t chain_len_of(uint32_t c)
 {
     if (c <= (uint32_t)MZ_CAP) return 0u;
     const uint32_t ex = (c - 1u) / (uint32_t)MZ_CAP;          // ceil((c - CAP) / CAP)
     return ex > (uint32_t)MZ_EMAX ? (uint32_t)MZ_EMAX : ex;
 }
-__host__ __device__ __forceinline__ uint32_t spilled_of(uint32_t c) { return c > MZ_CHAIN_CAP ? c - MZ_CHAIN_CAP : 0u; }
+__host__ __device__ __forceinline__ uint32_t extras_of(uint32_t c)
+{
+    const uint32_t s = seg_log_of(c);
+    return s ? ((1u << s) + 1u) * (uint32_t)MZ_EMAX + 1u : chain_len_of(c);       // one spare chain + the line a 7-line scan may touch
+}
+__host__ __device__ __forceinline__ uint32_t spilled_of(uint32_t c) { return c > MZ_CHAIN_CAP ? c - (uint32_t)MZ_CAP : 0u; }
 
-// per workgroup of RL_BUCKETS lines: extra lines, spilled k-mers, overflowing lines; overall: largest line
+// per workgroup of RL_BUCKETS lines: extra lines; overall: k-mers in segmented chains, overflowing lines, largest line, crowded lines
 static __global__ __launch_bounds__(RL_THREADS)
 void mz_extras_blocksum_kernel(const uint32_t *count, uint64_t n, uint32_t *blk_extra, unsigned long long *totals)
 {
     __shared__ uint32_t s_a[RL_THREADS / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
     uint32_t ex = 0, mx = 0;
-    unsigned long long sp = 0, ov = 0;
+    unsigned long long sp = 0, ov = 0, cr = 0;
     for (int i = 0; i < RL_PER_THREAD; i++) {
         const uint32_t c = (b0 + i < n) ? count[b0 + i] : 0u;
-        ex += extras_of(c); sp += spilled_of(c); ov += c > (uint32_t)MZ_CAP ? 1u : 0u;
+        ex += extras_of(c); sp += spilled_of(c); ov += c > (uint32_t)MZ_CAP ? 1u : 0u; cr += c > MZ_CHAIN_CAP ? 1u : 0u;
         mx = c > mx ? c : mx;
     }
     uint32_t te;
     block_exclusive_scan(ex, s_a, te);
     if (threadIdx.x == 0) blk_extra[blockIdx.x] = te;
-    for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); ov += __shfl_xor(ov, o, 64); const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+    for (int o = 32; o > 0; o >>= 1) { sp += __shfl_xor(sp, o, 64); ov += __shfl_xor(ov, o, 64); cr += __shfl_xor(cr, o, 64); const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
     if ((threadIdx.x & 63) == 0) {
         if (sp) atomicAdd(&totals[0], sp);
         if (ov) atomicAdd(&totals[1], ov);
         atomicMax(&totals[2], (unsigned long long)mx);
+        if (cr) atomicAdd(&totals[3], cr);
     }
 }
 
@@ -282,7 +303,7 @@ void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_ext
     for (int i = 0; i < RL_PER_THREAD; i++) {
         if (b0 + i >= n) break;
         uint32_t *hdr = reinterpret_cast<uint32_t *>(lines + (b0 + i) * MZ_LINE) + 30;
-        hdr[0] = extras_of(c[i]) | (spilled_of(c[i]) ? MZ_HDR_SPILL : 0u);
+        hdr[0] = chain_len_of(c[i]) | (seg_log_of(c[i]) << MZ_HDR_SEG_SHIFT);
         hdr[1] = (uint32_t)o;
         o += extras_of(c[i]);
     }
@@ -293,10 +314,9 @@ void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_ext
 // consecutive k-mers) between the first line and its extra lines, so a read crossing that region pays
 // the dependent extra-line fetch for every such run.  Here the chain is rewritten with whole groups
 // first: entries sorted by (size of their minimizer group, descending; minimizer key; k-mer).  One
-// WAVE per overflowing line, one lane per k-mer of its chain (at most MZ_CHAIN_CAP = 48; spilled k-mers
-// stay in the side table): group size and rank are counted against every other entry by broadcast, so
-// nothing is sorted in memory.  Without spills the result no longer depends on the order the atomics
-// happened to run in (with spills, WHICH k-mers spilled does; every lookup finds them either way).
+// WAVE per overflowing line, one lane per k-mer of its chain (at most MZ_CHAIN_CAP = 48; crowded lines keep
+// their arrival order): group size and rank are counted against every other entry by broadcast, so
+// nothing is sorted in memory.  The result no longer depends on the order the atomics happened to run in.
 static_assert(MZ_CHAIN_CAP <= 64, "one lane per chain entry");
 __global__ __launch_bounds__(256)
 void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint32_t m,
@@ -308,13 +328,12 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
     for (uint64_t base = wave * 64u; base < n_lines; base += n_waves * 64u) {
         const uint64_t mine = base + lane;
         const uint32_t n_mine = mine < n_lines ? count[mine] : 0u;
-        uint64_t todo = __ballot(n_mine > (uint32_t)MZ_CAP);
+        uint64_t todo = __ballot(n_mine > (uint32_t)MZ_CAP && n_mine <= MZ_CHAIN_CAP);
         while (todo) {
             const uint32_t l = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
             todo &= todo - 1u;
             const uint64_t i = base + l;
-            const uint32_t n_all = lane_bcast(n_mine, l);
-            const uint32_t n = n_all < MZ_CHAIN_CAP ? n_all : MZ_CHAIN_CAP;
+            const uint32_t n = lane_bcast(n_mine, l);
             uint8_t *first = lines + i * MZ_LINE;
             uint8_t *more = extra_lines + (uint64_t)reinterpret_cast<const uint32_t *>(first)[31] * MZ_LINE;
             auto slot_line = [&](uint32_t e) -> uint8_t * { return e < (uint32_t)MZ_CAP ? first : more + (uint64_t)(e / MZ_CAP - 1u) * MZ_LINE; };
@@ -348,8 +367,7 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
             for (int o = 32; o > 0; o >>= 1) bloom |= (uint32_t)__shfl_xor((int)bloom, o, 64);
             if (lane == 0) {
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
-                // extra_mask() sits in the high half; a line with spilled k-mers keeps their bits as well
-                hdr[0] = (n_all > MZ_CHAIN_CAP ? hdr[0] : (hdr[0] & 0xFFFFu)) | bloom;
+                hdr[0] = (hdr[0] & 0xFFFFu) | bloom;            // extra_mask() sits in the high half
             }
         }
     }
@@ -362,10 +380,8 @@ struct MzArgs {
     QueryArgs q;               // reads, outputs, shard range, div, k, maxhits, flags (lines unused)
     const uint8_t *lines;      // the primary lines this context owns
     const uint8_t *extra;      // extra lines
-    const uint8_t *side;       // side table (spilled k-mers), n_side lines
     uint32_t n_lines;          // lines the whole table is spread over (all shards)
     uint32_t line0, n_local;   // this context owns lines [line0, line0 + n_local)
-    uint32_t n_side;
     uint32_t m;
     double inv_htsize;         // 1/HTSIZE when the bucket-range filter may use rem_u64_fp, else 0
 };
@@ -703,14 +719,13 @@ void mz_query_kernel(const MzArgs A)
                                 // rare: lines beyond the first (Bloom bits are set only where extra lines exist)
                                 const uint32_t xm = extra_mask(c[s]);
                                 if (!hit[s] && (hdr & xm) == xm) {
-                                    const uint32_t extra = hdr & MZ_HDR_EXTRA;
-                                    // the chain, then (spill flag) the side table: lines addressed by the k-mer,
-                                    // probed until one that is not full
-                                    uint32_t sl = side_line_of(c[s], A.n_side);
-                                    for (uint32_t e = 0; !hit[s]; e++) {
-                                        const bool in_chain = e < extra;
-                                        if (!in_chain && !(hdr & MZ_HDR_SPILL)) break;
-                                        const uint8_t *X = in_chain ? A.extra + ((uint64_t)eb + e) * MZ_LINE : A.side + (uint64_t)sl * MZ_LINE;
+                                    // the chain of this line -- of a crowded line: the one of its 2^s chains this
+                                    // k-mer hashes to (s = 0 otherwise), and the one behind it when bit 8 says that
+                                    // some chain was full
+                                    const uint32_t extra = hdr & MZ_HDR_EXTRA;       // 7 = two chains of a crowded line (+ 1 line: harmless)
+                                    eb += seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * MZ_EMAX;
+                                    for (uint32_t e = 0; e < extra && !hit[s]; e++) {
+                                        const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
                                         u32x4 xv[MZ_CAP / 2];
 #pragma unroll
                                         for (int t = 0; t < MZ_CAP / 2; t++) xv[t] = reinterpret_cast<const u32x4 *>(X)[t];
@@ -721,11 +736,6 @@ void mz_query_kernel(const MzArgs A)
                                             if (key == c[s]) at = t;
                                         }
                                         if (at >= 0) { hit[s] = true; lab[s] = reinterpret_cast<const uint16_t *>(X + 8 * MZ_CAP)[at]; }
-                                        if (!in_chain) {
-                                            const uint64_t last = (uint64_t)xv[MZ_CAP / 2 - 1][2] | ((uint64_t)xv[MZ_CAP / 2 - 1][3] << 32);
-                                            if (last == MZ_EMPTY || e >= extra + A.n_side) break;      // a line with room ends the probe
-                                            sl = sl + 1u == A.n_side ? 0u : sl + 1u;
-                                        }
                                     }
                                 }
                             }

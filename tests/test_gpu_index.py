@@ -151,10 +151,11 @@ def _mmer_key_model(cw):
     return (t << 20) | (p >> 44)
 
 
-def test_one_minimizer_shared_by_100000_kmers_goes_to_the_side_table(gpu, oracle):
+def test_one_minimizer_shared_by_100000_kmers_is_spread_over_hashed_chains(gpu, oracle):
     """A conserved m-mer in thousands of contexts (a 16S-like region across many genomes): > 10^5 stored
-    k-mers share ONE minimizer line.  Its chain is capped (3 extra lines); the rest lives in the side table,
-    addressed by the k-mer; the index is kept for the whole table and every lookup is still exact."""
+    k-mers share ONE minimizer line.  A chain is capped at 3 extra lines; the crowded line gets 2^s chains and
+    a k-mer's chain is picked by a hash of the k-mer, so a lookup reads a bounded number of lines; the index
+    is kept for the whole table and every lookup is still exact."""
     k, ht, m = 21, 1000003, 11
     rng = np.random.default_rng(7)
     # an m-mer whose key is far below anything a random window offers
@@ -178,7 +179,7 @@ def test_one_minimizer_shared_by_100000_kmers_goes_to_the_side_table(gpu, oracle
     alll = np.concatenate([labels, lb0[keep]])
     sz, ky, lb = synth.db_from_kmers(allc, alll, ht)
     # reads: one k-mer each -- stored ones (hits), absent ones with the same minimizer (misses that walk the
-    # chain and probe the side table), plus ordinary reads
+    # hashed chain to its end), plus ordinary reads
     q = np.concatenate([stored[::3], absent, synth.revcomp(stored[1::50], k)])
     codes = np.zeros((q.size, k), dtype=np.uint8)
     for j in range(k):
@@ -194,7 +195,8 @@ def test_one_minimizer_shared_by_100000_kmers_goes_to_the_side_table(gpu, oracle
         info = db.db_info()
         got, rows = db.classify(rp, con, extended=True)
     assert info["index_kind"] == 1 and info["index_fallback"] == 0
-    assert info["largest_line"] >= 100000 and info["n_spilled_keys"] >= 100000 - 48 and info["n_side_lines"] > 10000
+    assert info["largest_line"] >= 100000 and info["n_spilled_keys"] >= 100000 - 48 and info["n_lines_crowded"] >= 1
+    assert 3 * 8192 <= info["n_extra_lines"] < 3 * 40000             # 2^s chains of 3 lines at ~9 k-mers per chain
     assert np.array_equal(rows, want_rows)
     assert np.array_equal(got, oracle.result_rows(want_rows))
     n_hit = (stored[::3].size + stored[1::50].size)

@@ -1,6 +1,8 @@
-"""Rate of the SHARDED query kernel on one GPU: the headline table cut into N bucket ranges, one of them
-loaded, every read of the batch looked up against it (sparse rows out), as each rank of an N-GPU sharded
-run does.  python tools/shard_rate.py [N ...]   (run on the GPU box)"""
+"""Rate of the query kernel on ONE part of a table that is spread over N GPUs, measured on one GPU: the
+headline table, part 0 of N loaded, every read of the batch looked up against it (sparse rows out), as each
+GPU of an N-GPU sharded job does.  Line-range parts (mc_load_db_part / mc_index_*: the default of mc_group
+and of bench.py --mode shard) and, for comparison, the reference's bucket ranges.
+    python tools/shard_rate.py [lines|buckets] [N ...]      (run on the GPU box)"""
 import os
 import sys
 import time
@@ -12,18 +14,30 @@ from jn_cuclark_amd import CuClarkDB, synth_gpu
 from jn_cuclark_amd.dist import shard_range
 
 K, HT, T, LAM, GLEN, MAXHITS = 31, 1610612741, 4096, 3.75, 100_000, 15
+args = sys.argv[1:]
+kind = "lines"
+if args and args[0] in ("lines", "buckets"):
+    kind = args.pop(0)
 dev = torch.device("cuda", 0)
 genomes = synth_gpu.make_genomes(T, GLEN, seed=31, device=dev)
 n_reads = 10_000_000
 rp, con = synth_gpu.make_reads(genomes, n_reads, 150, seed=32)
 rows = torch.zeros((n_reads, 2 * MAXHITS + 2), dtype=torch.int16, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
-for n in [int(a) for a in sys.argv[1:]] or [2, 8]:
-    shard = shard_range(HT, 0, n)
-    d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, K, HT, T, LAM, genomes=genomes, shard=shard)
+raw = synth_gpu.build_db(dev, 31, K, HT, T, LAM, genomes=genomes) if kind == "lines" else None
+for n in [int(a) for a in args] or [1, 2, 8]:
     db = CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=MAXHITS)
-    db.read_device(d_sz, d_keys, d_labels, shard=shard)
-    del d_sz, d_keys, d_labels
+    if kind == "lines":
+        t0 = time.time()
+        db.read_chunks(lambda: [(raw[0], raw[1], raw[2], 0, HT)], int(raw[1].numel()), part=0, n_parts=n, device=True)
+        build_s = time.time() - t0
+    else:
+        shard = shard_range(HT, 0, n)
+        d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, K, HT, T, LAM, genomes=genomes, shard=shard)
+        t0 = time.time()
+        db.read_device(d_sz, d_keys, d_labels, shard=shard)
+        build_s = time.time() - t0
+        del d_sz, d_keys, d_labels
     for _ in range(2):
         db.query_device(rp, con, None, rows, stream)
     torch.cuda.synchronize()
@@ -34,7 +48,8 @@ for n in [int(a) for a in sys.argv[1:]] or [2, 8]:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print("shard 1/%d of the table (%.1f GB index): %.2f ms per 10 M reads = %.0f Mreads/s per GPU, rows out"
-          % (n, db.db_info()["device_bytes"] / 1e9, ms, n_reads / ms / 1e3), flush=True)
+    info = db.db_info()
+    print("%s part 1/%d of the table (%.1f GB index, %.2fe9 k-mers owned, built in %.1f s): %.2f ms per 10 M reads = %.0f Mreads/s per GPU, rows out"
+          % (kind, n, info["device_bytes"] / 1e9, info["n_keys_owned"] / 1e9, build_s, ms, n_reads / ms / 1e3), flush=True)
     db.close()
     torch.cuda.empty_cache()
