@@ -1,22 +1,29 @@
-"""Multi-GPU classification: one process per GPU over torch.distributed (backend "nccl"
-is RCCL over xGMI on ROCm; "gloo" for the CPU rehearsal in tests/).
+"""Multi-GPU classification with one process per GPU over torch.distributed (backend "nccl" is RCCL over
+xGMI on ROCm; "gloo" for the CPU rehearsal in tests/).  The one-process form of the same protocol, for the
+host driver's `-d N`, is mc_group (include/mc_group.h).
 
-What the reference does (src/CuClarkDB.cu:552-559, :842-851, :909-928): the table is
-split into contiguous bucket ranges, one per device; EVERY device receives EVERY read
-batch and produces a partial sparse row per read; rows are pulled to device 0 with a
-blocking cudaMemcpyPeer binary tree and merged there; top-2 runs on device 0.
+What the reference does (src/CuClarkDB.cu:552-559, :842-851, :909-928): the table is split into contiguous
+bucket ranges, one per device; EVERY device receives EVERY read batch and produces a partial sparse row per
+read; rows are pulled to device 0 with a blocking cudaMemcpyPeer binary tree, merged pairwise there; top-2
+runs on device 0.
 
-What this module does instead (option 1): the same bucket-range
-shards, but the combine step is a reduce-scatter by read range -- one all_to_all in
-which rank j receives every rank's rows for reads [j*per, (j+1)*per), merges them and
-runs top-2 for those reads.  xGMI is point-to-point, so all 7 links of a GPU carry 1/8
-of the payload once, instead of log2(G) serialized hops into one GPU.  Rows are exact
-integers, so the result is bit-identical to the unsharded run for any shard count
-(tests/test_distributed.py, tests/test_gpu_parity.py::test_sharded_*).
+What this module does instead:
+  * parts are LINE ranges of the minimizer index (mc_load_db_part / CuClarkDB.read_part): the k-mers of one
+    minimizer run of a read live on ONE GPU, so a part fetches, matches and scores 1/G of the runs.  Bucket
+    ranges (the reference's partition, still accepted) scatter a run over all GPUs and every GPU fetches
+    nearly every line (tools/shard_rate.py);
+  * the combine step is a reduce-scatter by read range (option 1): one all_to_all in
+    which rank j receives every rank's rows for reads [j*per, (j+1)*per) -- xGMI is point-to-point, so all 7
+    links of a GPU carry 1/G of the rows once, instead of log2(G) serialized hops into one GPU -- then ONE
+    k-way merge + top-2 launch (mc_merge_result_device);
+  * a batch is cut into chunks: the exchange and merge of chunk i run on a second stream while the query
+    kernel works on chunk i+1; send and receive buffers are allocated once.
+Rows are exact integers, so the result is bit-identical to the unsharded run for any number of parts
+(tests/test_distributed.py, tests/test_gpu_index.py, tests/test_gpu_dist.py).
 
-`Replica` mode (table on every GPU, reads split) needs no exchange at all and is the
-throughput-optimal choice whenever the table fits one GPU (288 GB): sharding divides
-only the memory probes, every shard still encodes and hashes every k-mer.
+`Replica` mode (table on every GPU, reads split) needs no exchange at all and is the throughput-optimal
+choice whenever the table fits one GPU (288 GB): every part still encodes every read and finds its
+minimizers.
 """
 import torch
 import torch.distributed as dist
@@ -34,81 +41,147 @@ def read_range(n_reads, rank, world):
     return lo, min(n_reads, lo + per), per
 
 
+def chunk_bounds(n_reads, n_chunks):
+    n_chunks = max(1, min(n_chunks, n_reads)) if n_reads else 1
+    return [(n_reads * c // n_chunks, n_reads * (c + 1) // n_chunks) for c in range(n_chunks)]
+
+
 class ShardedClassifier:
     """`backend` provides, on this rank's device:
-         row_len
-         query_rows(reads_ptr, containers, n_reads) -> int16 tensor [n_reads, row_len]
-         merge_rows(a, b, n)      a <- union(a, b)   (first n rows)
-         result_rows(rows, n) -> int16 tensor [n, 5]
-    jn_cuclark_amd.dist.HipBackend wraps CuClarkDB; tests use an oracle-based double."""
+         row_len, device
+         query_rows_into(reads_ptr, containers, r0, r1, out)   rows of reads [r0, r1) of the batch -> out[:r1-r0]
+         merge_result(srcs, n)  ->  int16 tensor [n, 5]        k-way merge of the row tensors in `srcs` + top-2
+         stream handling (GPU only): current_stream / side_stream
+    jn_cuclark_amd.dist.HipBackend wraps CuClarkDB; tests use an oracle-based double on the CPU."""
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, n_chunks=4):
         self.be = backend
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.n_chunks = n_chunks
+        self._bufs = {}          # (slot, per) -> (send, recv)
+        self._gloo = dist.get_backend(group) == "gloo"
 
-    def exchange(self, rows, n_reads):
-        """all_to_all of partial rows: returns [world, per, row_len], slice j = rank j's
-        partial rows for MY read range."""
-        W, L = self.world, self.be.row_len
-        lo, hi, per = read_range(n_reads, self.rank, W)
-        send = torch.zeros((W * per, L), dtype=torch.int16, device=rows.device)
-        send[:n_reads] = rows[:n_reads]
+    def _buffers(self, slot, per):
+        key = (slot, per)
+        if key not in self._bufs:
+            W, L = self.world, self.be.row_len
+            send = torch.zeros((W * per, L), dtype=torch.int16, device=self.be.device)
+            recv = torch.zeros((W * per, L), dtype=torch.int16, device=self.be.device)
+            self._bufs[key] = (send, recv)
+        return self._bufs[key]
+
+    def _all_to_all(self, send, recv):
         # bytes on the wire: neither RCCL nor gloo has a 16-bit integer type
-        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+        s8, r8 = send.view(torch.uint8).view(-1), recv.view(torch.uint8).view(-1)
+        if send.is_cuda and self._gloo:
             # rehearsal on a box without RCCL peers: stage through the host
-            s8 = send.view(torch.uint8).view(-1).cpu()
-            r8 = torch.empty_like(s8)
-            dist.all_to_all_single(r8, s8, group=self.group)
-            recv = r8.to(send.device).view(torch.int16).view(W * per, L)
+            hs = s8.cpu()
+            hr = torch.empty_like(hs)
+            dist.all_to_all_single(hr, hs, group=self.group)
+            r8.copy_(hr)
         else:
-            recv = torch.empty_like(send)
-            dist.all_to_all_single(recv.view(torch.uint8).view(-1), send.view(torch.uint8).view(-1), group=self.group)
-        return recv.view(W, per, L), (lo, hi, per)
+            dist.all_to_all_single(r8, s8, group=self.group)
 
     def classify(self, reads_ptr, containers, n_reads):
-        """Every rank passes the SAME batch.  Returns (final int16 [hi-lo, 5], (lo, hi)):
-        the final rows of this rank's read range."""
-        rows = self.be.query_rows(reads_ptr, containers, n_reads)
-        recv, (lo, hi, per) = self.exchange(rows, n_reads)
-        mine = hi - lo
-        acc = recv[0]
-        for j in range(1, self.world):           # fixed order: integer adds, any order is exact
-            self.be.merge_rows(acc, recv[j], mine)
-        return self.be.result_rows(acc, mine), (lo, hi)
+        """Every rank passes the SAME batch.  Returns (final int16 [mine, 5], ranges): the final rows of the
+        reads this rank owns -- for every chunk [c0, c1) of the batch the read range `rank` of it --
+        concatenated in read order, and those ranges as (lo, hi) pairs."""
+        W = self.world
+        gpu = self.be.device.type == "cuda"
+        outs, ranges = [], []
+        if gpu:
+            main = torch.cuda.current_stream(self.be.device)
+            side = self.be.side_stream()
+            side.wait_stream(main)
+        for ci, (c0, c1) in enumerate(chunk_bounds(n_reads, self.n_chunks)):
+            m = c1 - c0
+            lo, hi, per = read_range(m, self.rank, W)
+            send, recv = self._buffers(ci & 1, per)
+            if gpu and ci >= 2:
+                main.wait_event(self._done[ci & 1])              # the slot's previous exchange has read `send`
+            # rows of the chunk straight into the send layout (row i of the chunk = read c0 + i)
+            self.be.query_rows_into(reads_ptr, containers, c0, c1, send)
+            if gpu:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                ctx = torch.cuda.stream(side)
+            else:
+                ctx = _Null()
+            with ctx:
+                self._all_to_all(send, recv)
+                mine = hi - lo
+                srcs = [recv[j * per: j * per + mine] for j in range(W)]   # rank j's rows for MY reads of the chunk
+                outs.append(self.be.merge_result(srcs, mine))
+                if gpu:
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    if not hasattr(self, "_done"):
+                        self._done = [None, None]
+                    self._done[ci & 1] = done
+            ranges.append((c0 + lo, c0 + hi))
+        if gpu:
+            main.wait_stream(side)
+        fin = torch.cat(outs) if outs else torch.zeros((0, 5), dtype=torch.int16, device=self.be.device)
+        return fin, ranges
 
     def classify_gathered(self, reads_ptr, containers, n_reads):
-        """As classify(), then all_gather so every rank holds all final rows."""
-        fin, (lo, hi) = self.classify(reads_ptr, containers, n_reads)
-        _, _, per = read_range(n_reads, self.rank, self.world)
-        pad = torch.zeros((per, 5), dtype=torch.int16, device=fin.device)
-        pad[: hi - lo] = fin
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather([o.view(torch.uint8) for o in out], pad.view(torch.uint8), group=self.group)
-        return torch.cat(out)[:n_reads]
+        """As classify(), then all_gather so every rank holds all final rows in read order."""
+        fin, ranges = self.classify(reads_ptr, containers, n_reads)
+        W = self.world
+        per_max = sum(read_range(c1 - c0, 0, W)[2] for c0, c1 in chunk_bounds(n_reads, self.n_chunks))
+        pad = torch.zeros((per_max, 5), dtype=torch.int16, device=fin.device)
+        pad[: fin.shape[0]] = fin
+        out = [torch.empty_like(pad) for _ in range(W)]
+        if fin.is_cuda and self._gloo:
+            host = [o.cpu().view(torch.uint8) for o in out]
+            dist.all_gather(host, pad.cpu().view(torch.uint8), group=self.group)
+            out = [h.view(torch.int16).to(fin.device) for h in host]
+        else:
+            dist.all_gather([o.view(torch.uint8) for o in out], pad.view(torch.uint8), group=self.group)
+        full = torch.zeros((n_reads, 5), dtype=torch.int16, device=fin.device)
+        for j in range(W):
+            at = 0
+            for c0, c1 in chunk_bounds(n_reads, self.n_chunks):
+                lo, hi, _ = read_range(c1 - c0, j, W)
+                full[c0 + lo: c0 + hi] = out[j][at: at + hi - lo]
+                at += hi - lo
+        return full
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class HipBackend:
-    """ShardedClassifier backend over a CuClarkDB holding this rank's bucket range."""
+    """ShardedClassifier backend over a CuClarkDB holding this rank's part of the table."""
 
     def __init__(self, db, device):
         self.db = db
-        self.device = device
+        self.device = torch.device(device)
         self.row_len = db.row_len
+        self._side = None
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def query_rows(self, reads_ptr, containers, n_reads):
-        rows = torch.empty((n_reads, self.row_len), dtype=torch.int16, device=self.device)
-        self.db.query_device(reads_ptr, containers, rows_t=rows, stream=self._stream())
-        return rows
+    def query_rows_into(self, reads_ptr, containers, r0, r1, out):
+        # the offsets of reads [r0, r1] stay absolute: the kernel indexes the whole container array with them
+        self.db.query_device(reads_ptr[r0: r1 + 1], containers, rows_t=out, stream=self._stream())
 
-    def merge_rows(self, a, b, n):
-        self.db.merge_rows_device(a, b, a, n, stream=self._stream())
-
-    def result_rows(self, rows, n):
+    def merge_result(self, srcs, n):
         fin = torch.empty((n, 5), dtype=torch.int16, device=self.device)
-        self.db.result_rows_device(rows, fin, n, stream=self._stream())
+        if n:
+            self.db.merge_result_device(srcs, n, final_t=fin, stream=self._stream())
         return fin

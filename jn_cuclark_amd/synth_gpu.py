@@ -164,3 +164,97 @@ def make_reads(genomes, n_reads, length, seed, planted_frac=0.5, sub_rate=0.01, 
     if return_truth:      # source genome of every planted read (the first n_planted reads)
         return ptr, out.reshape(-1), (torch.cat(truth) if truth else torch.zeros(0, dtype=torch.int64, device=device))
     return ptr, out.reshape(-1)
+
+
+# --------------------------------------------------------------------------------------------------
+# genome-shaped table: EVERY stored k-mer comes from a genome, next to its neighbours
+# --------------------------------------------------------------------------------------------------
+def make_structured_genomes(n_targets, length, seed, device, genus=4, divergence=0.05,
+                            conserved_len=1500, conserved_div=0.03, tandem_len=2000, polya_len=500):
+    """Genomes with the structure real ones have and uniform random ones lack:
+      * species of one "genus" (`genus` consecutive targets) descend from a common ancestor with `divergence`
+        substitutions: a fifth of their 31-mers is shared inside the genus (not discriminative);
+      * one conserved block (16S-like) sits in EVERY genome with `conserved_div` substitutions per genome:
+        conserved m-mers in thousands of different contexts (crowded minimizers);
+      * a tandem repeat (a random 7-mer unit, `tandem_len` bases) in every genome: few distinct k-mers, each
+        many times in ONE target;
+      * a poly-A run in every tenth genome: one k-mer in many targets.
+    Returns uint8 codes [n_targets, length]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_gen = (n_targets + genus - 1) // genus
+    anc = torch.randint(0, 4, (n_gen, length), dtype=torch.uint8, device=device, generator=g)
+    out = anc.repeat_interleave(genus, dim=0)[:n_targets].contiguous()
+    del anc
+    rows = 256
+    for s in range(0, n_targets, rows):
+        e = min(n_targets, s + rows)
+        mut = torch.rand((e - s, length), device=device, generator=g) < divergence
+        delta = torch.randint(1, 4, (e - s, length), dtype=torch.uint8, device=device, generator=g)
+        out[s:e] = torch.where(mut, (out[s:e] + delta) & 3, out[s:e])
+    cons = torch.randint(0, 4, (conserved_len,), dtype=torch.uint8, device=device, generator=g)
+    pos = torch.randint(0, length - conserved_len - tandem_len - polya_len - 64, (n_targets,), device=device, generator=g)
+    mut = torch.rand((n_targets, conserved_len), device=device, generator=g) < conserved_div
+    delta = torch.randint(1, 4, (n_targets, conserved_len), dtype=torch.uint8, device=device, generator=g)
+    block = torch.where(mut, (cons[None, :] + delta) & 3, cons[None, :].expand(n_targets, -1))
+    ar = torch.arange(conserved_len, device=device)[None, :]
+    out.scatter_(1, pos[:, None] + ar, block)
+    unit = torch.randint(0, 4, (n_targets, 7), dtype=torch.uint8, device=device, generator=g)
+    tr = unit.repeat(1, tandem_len // 7 + 1)[:, :tandem_len]
+    out.scatter_(1, (pos + conserved_len + 32)[:, None] + torch.arange(tandem_len, device=device)[None, :], tr)
+    pa = torch.arange(0, n_targets, 10, device=device)
+    out[pa[:, None], (pos[pa] + conserved_len + tandem_len + 64)[:, None] + torch.arange(polya_len, device=device)[None, :]] = 3
+    return out
+
+
+def build_genome_db(genomes, k, htsize, n_ranges=16, slab=256):
+    """The discriminative k-mers of `genomes` (canonical k-mers that occur in exactly one target, once per
+    target: reference RemoveCommon, src/HashTableStorage_hh.hh:229-280) as bucket-order chunks
+    [(d_sz uint8[nb], d_keys int32[n], d_labels int16[n], b0, b1), ...] -- the array form of the on-disk
+    format, one chunk per bucket range, ready for CuClarkDB.read_chunks(device=True).  k <= 31."""
+    dev = genomes.device
+    T, L = genomes.shape
+    canon = []                                   # canonical k-mers of every genome, slab by slab (8 bytes per base)
+    for s in range(0, T, slab):
+        km = kmers_t(genomes[s:min(T, s + slab)], k)
+        canon.append(torch.minimum(km, revcomp_t(km, k)))
+        del km
+    chunks = []
+    total = 0
+    for j in range(n_ranges):
+        b0, b1 = htsize * j // n_ranges, htsize * (j + 1) // n_ranges
+        cs, ls = [], []
+        for i, c in enumerate(canon):
+            r = c % htsize
+            keep = (r >= b0) & (r < b1)
+            del r
+            lab = torch.arange(i * slab, i * slab + c.shape[0], device=dev, dtype=torch.int16)[:, None].expand_as(c)
+            cs.append(c[keep])
+            ls.append(lab[keep])
+            del keep, lab
+        c = torch.cat(cs)
+        lab = torch.cat(ls)
+        del cs, ls
+        c, order = torch.sort(c)
+        lab = lab[order]
+        del order
+        first = torch.ones(c.numel(), dtype=torch.bool, device=dev)
+        first[1:] = c[1:] != c[:-1]
+        run = torch.cumsum(first.to(torch.int32), 0) - 1
+        start = torch.nonzero(first).squeeze(1)
+        lab0 = lab[start]
+        bad = torch.zeros(start.numel(), dtype=torch.int32, device=dev)
+        bad.index_add_(0, run, (lab != lab0[run]).to(torch.int32))
+        good = bad == 0
+        c, lab = c[start][good], lab0[good]
+        del first, run, start, lab0, bad, good
+        comp, order = torch.sort(((c % htsize) << 32) | (c // htsize))       # bucket, then quotient: the file order
+        lab = lab[order]
+        del c, order
+        sz = torch.bincount((comp >> 32) - b0, minlength=b1 - b0)
+        if int(sz.max().item()) > 255:
+            raise ValueError("a bucket holds more than 255 k-mers (the on-disk format has one byte per bucket)")
+        chunks.append((sz.to(torch.uint8), (comp & 0xFFFFFFFF).to(torch.int32), lab.contiguous(), b0, b1))
+        total += int(lab.numel())
+        del comp, sz, lab
+    return chunks, total

@@ -1,0 +1,48 @@
+"""Worker for tests/test_gpu_dist.py: the sharded protocol of jn_cuclark_amd.dist with the REAL backend
+(HipBackend over libmcclark.so) on every rank; ranks share the one card of the test box and talk over gloo
+(no RCCL peers there).  Rank r holds line-range part r of the table in the files."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from jn_cuclark_amd import CuClarkDB                                  # noqa: E402
+from jn_cuclark_amd.dist import ShardedClassifier, HipBackend        # noqa: E402
+
+
+def main():
+    inp, out = sys.argv[1], sys.argv[2]
+    d = np.load(inp, allow_pickle=False)
+    k, ht, base = int(d["k"]), int(d["htsize"]), str(d["base"])
+    dist.init_process_group("gloo")                      # before anything touches the GPU
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    rp = torch.from_numpy(d["rp"].view(np.int32)).to(dev)
+    con = torch.from_numpy(d["con"].view(np.int16)).to(dev)
+    n = rp.numel() - 1
+    with CuClarkDB(k=k, numBatches=1, numTargets=int(d["targets"]), device=0, htsize=ht, maxhits=15) as db:
+        assert db.read_part(base, rank, world) is True
+        info = db.db_info()
+        assert info["part"] == rank and info["n_parts"] == world and info["index_kind"] == 1
+        sc = ShardedClassifier(HipBackend(db, dev), n_chunks=int(d["chunks"]))
+        full = sc.classify_gathered(rp, con, n)
+        again, ranges = sc.classify(rp, con, n)          # buffers are reused: same answer
+        torch.cuda.synchronize()
+        assert torch.equal(again, torch.cat([full[lo:hi] for lo, hi in ranges]))
+        owned = torch.tensor([info["n_keys_owned"]], dtype=torch.int64)
+        dist.all_reduce(owned)
+        assert int(owned.item()) == info["n_keys"]
+    if rank == 0:
+        np.save(out, full.cpu().numpy().view(np.uint16))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,17 +24,17 @@ K, HT, MAXHITS = 21, 1000003, 15
 class OracleBackend:
     def __init__(self, odb, part):
         self.odb, self.part, self.row_len = odb, part, 2 * MAXHITS + 2
+        self.device = torch.device("cpu")
 
-    def query_rows(self, rp, con, n):
-        rows, _ = self.odb.query_rows(K, rp.numpy().view(np.uint32), con.numpy().view(np.uint16), MAXHITS, part=self.part)
-        return torch.from_numpy(rows.view(np.int16))
+    def query_rows_into(self, rp, con, r0, r1, out):
+        rows, _ = self.odb.query_rows(K, rp[r0:r1 + 1].numpy().view(np.uint32).copy(), con.numpy().view(np.uint16), MAXHITS, part=self.part)
+        out[: r1 - r0] = torch.from_numpy(rows.view(np.int16))
 
-    def merge_rows(self, a, b, n):
-        m = pyoracle.merge_rows(a[:n].numpy().view(np.uint16), b[:n].numpy().view(np.uint16))
-        a[:n] = torch.from_numpy(m.view(np.int16))
-
-    def result_rows(self, rows, n):
-        return torch.from_numpy(pyoracle.result_rows(rows[:n].numpy().view(np.uint16)).view(np.int16))
+    def merge_result(self, srcs, n):
+        acc = srcs[0][:n].numpy().view(np.uint16).copy()
+        for s in srcs[1:]:
+            acc = pyoracle.merge_rows(acc, s[:n].numpy().view(np.uint16).copy())
+        return torch.from_numpy(pyoracle.result_rows(acc).view(np.int16)).reshape(n, 5)
 
 
 def main():
@@ -46,10 +46,10 @@ def main():
     codes, _ = synth.sample_reads(genomes, n_reads, 150, seed=6)
     rp, con = synth.pack_uniform(codes)
     odb = pyoracle.OracleDB.from_arrays(HT, sz, ky, lb)
-    sc = ShardedClassifier(OracleBackend(odb, shard_range(HT, rank, world)))
+    sc = ShardedClassifier(OracleBackend(odb, shard_range(HT, rank, world)), n_chunks=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
     fin = sc.classify_gathered(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
-    part, (lo, hi) = sc.classify(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
-    assert torch.equal(part, fin[lo:hi])
+    part, ranges = sc.classify(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
+    assert torch.equal(part, torch.cat([fin[lo:hi] for lo, hi in ranges]))
     if rank == 0:
         want, _ = odb.classify(K, rp, con, MAXHITS)
         np.savez(out, got=fin.numpy().view(np.uint16), want=want)

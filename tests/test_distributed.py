@@ -10,14 +10,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,n_reads", [(2, 501), (3, 200), (2, 1)])
-def test_sharded_protocol_on_gloo(world, n_reads, tmp_path):
+@pytest.mark.parametrize("world,n_reads,chunks", [(2, 501, 4), (3, 200, 3), (2, 1, 4), (2, 7, 1)])
+def test_sharded_protocol_on_gloo(world, n_reads, chunks, tmp_path):
     out = str(tmp_path / "res.npz")
-    port = 29600 + world * 7 + n_reads % 50
+    port = 29600 + world * 7 + n_reads % 50 + chunks
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_reads)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_reads), str(chunks)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = np.load(out)
