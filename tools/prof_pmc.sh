@@ -6,10 +6,11 @@ set -u
 TAG=${1:-pmc}; shift || true
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --verify 0 $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --verify 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $f; grep "query_kernel" $f; } > $OUT/kernel_stats_query.csv
+cp $f $OUT/all_kernel_stats.csv
 i=0
 for grp in \
   "FETCH_SIZE TCC_HIT_sum" \
@@ -39,3 +40,4 @@ PY
 done
 rm -rf $OUT/trace/*/*kernel_trace.csv
 cat $OUT/kernel_stats_query.csv; cat $OUT/pmc_query.txt
+python3 tools/update_traffic.py $OUT/pmc_query.txt $OUT/bench_trace.json > $OUT/traffic.json && cp profiles/traffic.json $OUT/traffic_profiles.json

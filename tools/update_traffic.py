@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""tools/update_traffic.py <pmc_query.txt> <bench_trace.json> -- turn the FETCH_SIZE / WRITE_SIZE rows of a
+tools/prof_pmc.sh run into profiles/traffic.json, keyed by the workload and by the hash of the kernel sources
+(bench.py uses the figure only for exactly that build and workload)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+vals = {}
+for ln in open(sys.argv[1]):
+    p = ln.split("\t")
+    if len(p) >= 3 and p[2].startswith("avg_per_launch="):
+        vals[p[0]] = float(p[2].split("=")[1])
+line = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+line_bytes = 128 if line["roofline"]["index"] == "minimizer" else 64
+# MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes
+hbm = (2.0 if line_bytes == 128 else 1.0) * fetch_kb * 1024 + write_kb * 1024
+out = {
+    "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, average per launch of %s)" % (
+        os.path.relpath(sys.argv[1], ROOT), line["roofline"]["kernel"]),
+    "kernel": line["roofline"]["kernel"], "htsize": line["config"]["htsize"], "db": line["config"].get("db", "synthetic"),
+    "reads_per_launch": line["config"]["reads_per_step"], "read_len": 150, "line_bytes": line_bytes,
+    "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "hbm_bytes_per_launch": int(hbm),
+    "rdreq": vals.get("TCC_EA0_RDREQ_sum"),
+    "source_sha": bench.source_sha(),
+    "correction": "FETCH_SIZE x 2 for 128-byte requests (MI355X_MICROARCH.md, HBM section: gfx950 tallies a 128-byte request as "
+                  "64 bytes), cross-checked by TCC_EA0_RDREQ x 128 B; 64-byte requests (bucket-line kernel) are exact.",
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out))
