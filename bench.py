@@ -110,12 +110,23 @@ def main():
             args.genome_len = 1_500_000
         genomes = synth_gpu.make_structured_genomes(args.targets, args.genome_len, seed=31, device=dev)
         chunks, n_keys = synth_gpu.build_genome_db(genomes, k, ht)
-        if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.verify == 0):
-            raw_host = tuple(np.concatenate([c[i].cpu().numpy() for c in chunks]) for i in range(3))
-        # line-range parts when sharded: every rank streams the whole table and keeps its lines
-        db.read_chunks(lambda: chunks, n_keys, part=rank if shard_mode else 0, n_parts=world if shard_mode else 1, device=True)
         nonempty = float(sum(int((c[0] != 0).sum().item()) for c in chunks)) / ht if rank == 0 else 0.0
+        # The table goes to the host and every temporary of the generator back to the driver BEFORE the index is
+        # allocated: 140 GB of lines carved out of a heap that torch has fragmented end up on small pages, and the
+        # query kernel (one TLB miss per line) then runs anywhere between 630 and 910 Mreads/s on the same table.
+        # A loader that starts from files (mc_load_db) allocates from a fresh heap and does not have this problem.
+        host = [(c[0].cpu().numpy(), c[1].cpu().numpy(), c[2].cpu().numpy(), c[3], c[4]) for c in chunks]
         del chunks
+        genomes_h = genomes.cpu()
+        del genomes
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.verify == 0):
+            raw_host = tuple(np.concatenate([c[i] for c in host]) for i in range(3))
+        # line-range parts when sharded: every rank streams the whole table and keeps its lines
+        db.read_chunks(lambda: host, n_keys, part=rank if shard_mode else 0, n_parts=world if shard_mode else 1, device=False)
+        del host
+        genomes = genomes_h.to(dev)
+        del genomes_h
     else:
         genomes = synth_gpu.make_genomes(args.targets, args.genome_len, seed=31, device=dev)
         d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, k, ht, args.targets, args.lam, genomes=genomes)
@@ -179,6 +190,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kern_ms_avg = sum(kern_ms) / len(kern_ms)
+    if rank == 0:
+        log("step times (ms, sorted): " + " ".join("%.3f" % t for t in kern_ms))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -229,6 +242,7 @@ def main():
                 "db": args.db,
                 "index": {"kind": index, "fallback": bool(info["index_fallback"]),
                           "lines": info["line_end"] - info["line_begin"], "extra_lines": info["n_extra_lines"],
+                          "kmers_per_line": round(n_keys / max(1, info["n_lines"]), 2),
                           "lines_overflowing_frac": round(info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]), 5),
                           "lines_crowded": info["n_lines_crowded"], "kmers_in_hashed_chains": info["n_spilled_keys"],
                           "largest_line_kmers": info["largest_line"], "hbm_bytes": info["device_bytes"]},

@@ -101,8 +101,16 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
         return fail(MC_EINVAL, "the minimizer index needs k >= 16 and a minimizer space above the line count");
     free_db(c);
     index_abort(c);
-    double per_line = 6.0;
+    // k-mers per 12-slot line.  Fewer per line = fewer overflowing lines = a faster kernel (genome-shaped table,
+    // 5.5e9 k-mers: 4 / 5 / 6 / 8 per line -> 993 / 913 / 828 / 705 Mreads/s at 193 / 161 / 140 / 126 GB), so a table
+    // that is alone on the card takes the room it finds: the sparsest fill in [4, 8] that leaves 16 GB free.
+    // Parts of one table must agree on the line space and use the default (the group loader picks for all).
+    double per_line = c->fill_hint > 0.0 ? c->fill_hint : 6.0;
     if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
+    else if (c->fill_hint <= 0.0 && n_parts == 1) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) per_line = mcint::choose_fill(n_keys_total, 1, fr);
+    }
     const uint64_t want = (uint64_t)((double)n_keys_total / per_line) + 1024;
     if (want >= 0xFFFFFFF0ull) return fail(MC_EINVAL, "minimizer index: too many lines");
     const uint32_t n_lines = (uint32_t)want;
@@ -613,11 +621,42 @@ int DbFileStream::pass(const ChunkFn &f)
     return MC_OK;
 }
 
+// HBM one context needs for its share of a minimizer index at `fill` k-mers per line: lines, extra lines (the
+// share measured on a genome-shaped table, which overflows more than a random one), build counters
+uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill)
+{
+    const double extra = fill <= 4.0 ? 0.12 : fill <= 5.0 ? 0.17 : fill <= 6.0 ? 0.22 : fill <= 7.0 ? 0.32 : 0.45;
+    const double lines = ((double)n_keys_total / fill + 1024.0) / (double)n_parts;
+    return (uint64_t)(lines * 128.0 * (1.0 + extra) + lines * 4.0) + (2ull << 30);
+}
+
+double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes)
+{
+    const uint64_t reserve = 16ull << 30;
+    for (double f = 4.0; f < 8.0; f += 0.5)
+        if (index_bytes(n_keys_total, n_parts, f) + reserve <= free_bytes) return f;
+    return 8.0;
+}
+
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode == 1 && mz_eligible(c, n_keys_total); }
 
 int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_parts)
 {
     int rc = MC_OK;
+    if (!getenv("MC_MZ_FILL")) {
+        // one fill for all members: what the member with the least free HBM can afford
+        uint64_t free_min = ~0ull;
+        for (uint32_t i = 0; i < n; i++) {
+            size_t fr = 0, tot = 0;
+            if (set_dev(ctxs[i]) != MC_OK || hipMemGetInfo(&fr, &tot) != hipSuccess) continue;
+            uint32_t sharing = 0;
+            for (uint32_t o = 0; o < n; o++) sharing += ctxs[o]->device == ctxs[i]->device ? 1u : 0u;
+            free_min = std::min<uint64_t>(free_min, fr / sharing);
+        }
+        if (const char *e = getenv("MC_GROUP_HBM_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) free_min = std::min(free_min, v); }
+        const double f = choose_fill(F.n_keys_kept, line_parts ? n : 1, free_min);
+        for (uint32_t i = 0; i < n; i++) ctxs[i]->fill_hint = f;
+    }
     auto abort_all = [&]() { const std::string keep = g_err; for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); free_db(ctxs[i]); index_abort(ctxs[i]); } g_err = keep; };
     for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
         rc = set_dev(ctxs[i]);

@@ -105,10 +105,9 @@ int free_batches(mc_group *g)
 uint64_t bytes_for_table(const mc_ctx *c, uint64_t n_keys, uint64_t nb)
 {
     if (mcint::minimizer_index_possible(c, n_keys)) {
-        double per_line = 6.0;
+        double per_line = 8.0;          // the densest fill the loader would fall back to
         if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
-        const uint64_t n_lines = (uint64_t)((double)n_keys / per_line) + 1024;
-        return n_lines * 128 + n_lines * 128 / 25 + n_lines * 4 + (3ull << 30);     // lines, ~4 % extra lines, counters, chunk staging
+        return mcint::index_bytes(n_keys, 1, per_line);
     }
     return nb * 128 + n_keys * 14;        // bucket lines (worst case 128 B) next to the raw arrays during the fill
 }

@@ -96,6 +96,7 @@ struct mc_ctx {
     uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
     uint32_t mz_n_lines = 0;           // lines of the whole table (all parts)
     uint32_t mz_line0 = 0, mz_n_local = 0, mz_m = 0;
+    double fill_hint = 0.0;            // k-mers per line chosen by a group loader for all its members (0 = choose here)
     mcint::IndexBuild build;
 
     unsigned long long *d_over = nullptr;
@@ -145,5 +146,7 @@ struct DbFileStream {
 // hold its lines.
 int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_parts);
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total);
+uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill);
+double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes);
 
 } // namespace mcint

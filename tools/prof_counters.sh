@@ -5,7 +5,7 @@ set -u
 TAG=$1; shift
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --verify 0"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --verify 0 ${BENCH_ARGS:-}"
 i=0
 for grp in "$@"; do
   i=$((i+1))
