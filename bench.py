@@ -338,8 +338,8 @@ def main():
         watchdog.daemon = True
         watchdog.start()
     if world > 1 and not shard_mode and not args.no_shard_check:
-        del d_sz, d_keys, d_labels
         db.close()
+        del rp_t, con_t, fin_t
         torch.cuda.empty_cache()
         chk = shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend)
         if rank == 0:
