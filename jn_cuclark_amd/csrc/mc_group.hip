@@ -51,6 +51,8 @@ struct mc_group {
     bool loaded = false;
     std::vector<GBatch> batches;
     std::vector<GSlot> slots;        // [member * 2 + slot]
+    uint8_t *h_slab = nullptr;       // the pinned buffers of all batches
+    std::vector<uint8_t *> d_slab;   // per member: the device buffers of its two slots
     uint64_t max_reads = 0, max_con = 0, per = 0;
     bool want_rows = false;
     // batches may be submitted in any order (the host packs them on several threads): slots and, for
@@ -76,11 +78,9 @@ int free_batches(mc_group *g)
         (void)hipSetDevice(g->ctx[m]->device);
         (void)hipDeviceSynchronize();
     }
+    if (g->h_slab) (void)hipHostFree(g->h_slab);
+    g->h_slab = nullptr;
     for (auto &b : g->batches) {
-        if (b.h_ptr) (void)hipHostFree(b.h_ptr);
-        if (b.h_con) (void)hipHostFree(b.h_con);
-        if (b.h_final) (void)hipHostFree(b.h_final);
-        if (b.h_rows) (void)hipHostFree(b.h_rows);
         for (size_t m = 0; m < b.done.size(); m++)
             if (b.done[m]) { (void)hipSetDevice(g->ctx[m]->device); (void)hipEventDestroy(b.done[m]); }
     }
@@ -89,15 +89,12 @@ int free_batches(mc_group *g)
     for (size_t i = 0; i < g->slots.size(); i++) {
         GSlot &s = g->slots[i];
         (void)hipSetDevice(g->ctx[i / 2]->device);
-        if (s.d_ptr) (void)hipFree(s.d_ptr);
-        if (s.d_con) (void)hipFree(s.d_con);
-        if (s.d_rows) (void)hipFree(s.d_rows);
-        if (s.d_recv) (void)hipFree(s.d_recv);
-        if (s.d_final) (void)hipFree(s.d_final);
-        if (s.d_merged) (void)hipFree(s.d_merged);
         if (s.ev_query) (void)hipEventDestroy(s.ev_query);
     }
     g->slots.clear();
+    for (size_t m = 0; m < g->d_slab.size(); m++)
+        if (g->d_slab[m]) { (void)hipSetDevice(g->ctx[m]->device); (void)hipFree(g->d_slab[m]); }
+    g->d_slab.clear();
     return MC_OK;
 }
 
@@ -285,14 +282,23 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
         return fail(MC_ENOMEM, std::string(what) + ": " + hipGetErrorString(e) + " -- use more, smaller batches (-b)");
     };
     int rc = mcint::set_dev(g->ctx[0]); if (rc) return rc;
+    // ONE pinned allocation for the buffers of all batches and ONE device allocation per member: pinning and
+    // mapping cost per call, and 4 x n_batches calls were a third of a 2 M-read run (38 ms).
+    auto up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+    const size_t b_ptr = up((max_reads + 1) * 4), b_con = up(max_con * 2), b_fin = up(max_reads * MC_FINAL_ROW * 2),
+                 b_rows = g->want_rows ? up(max_reads * row_len * 2) : 0;
+    const size_t per_batch = b_ptr + b_con + b_fin + b_rows;
+    // portable: every device of the group copies from / into these
+    hipError_t e = hipHostMalloc((void **)&g->h_slab, per_batch * n_batches, hipHostMallocPortable);
+    if (e != hipSuccess) return oom("pinned batch buffers", e);
     g->batches.resize(n_batches);
-    for (auto &b : g->batches) {
-        // portable: every device of the group copies from / into these
-        hipError_t e = hipHostMalloc((void **)&b.h_ptr, (max_reads + 1) * 4, hipHostMallocPortable);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_con, max_con * 2, hipHostMallocPortable);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_final, max_reads * MC_FINAL_ROW * 2, hipHostMallocPortable);
-        if (e == hipSuccess && g->want_rows) e = hipHostMalloc((void **)&b.h_rows, max_reads * row_len * 2, hipHostMallocPortable);
-        if (e != hipSuccess) return oom("pinned batch buffers", e);
+    for (uint32_t i = 0; i < n_batches; i++) {
+        GBatch &b = g->batches[i];
+        uint8_t *base = g->h_slab + per_batch * i;
+        b.h_ptr = (uint32_t *)base;
+        b.h_con = (uint16_t *)(base + b_ptr);
+        b.h_final = (uint16_t *)(base + b_ptr + b_con);
+        b.h_rows = g->want_rows ? (uint16_t *)(base + b_ptr + b_con + b_fin) : nullptr;
         b.done.assign(n, nullptr);
         for (uint32_t m = 0; m < n; m++) {
             if ((rc = mcint::set_dev(g->ctx[m])) != MC_OK) { free_batches(g); return rc; }
@@ -301,23 +307,28 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
         }
     }
     g->slots.resize((size_t)n * 2);
+    g->d_slab.assign(n, nullptr);
+    const size_t d_ptr = up((max_reads + 1) * 4), d_con = up(max_con * 2);
+    const size_t d_rows = shards ? up(max_reads * row_len * 2) : (g->want_rows ? up(max_reads * row_len * 2) : 0);
+    const size_t d_recv = shards ? up((size_t)(n > 1 ? n - 1 : 1) * g->per * row_len * 2) : 0;
+    const size_t d_fin = up((shards ? g->per : max_reads) * MC_FINAL_ROW * 2);
+    const size_t d_mrg = shards && g->want_rows ? up(g->per * row_len * 2) : 0;
+    const size_t per_slot = d_ptr + d_con + d_rows + d_recv + d_fin + d_mrg;
     for (uint32_t m = 0; m < n; m++) {
         if ((rc = mcint::set_dev(g->ctx[m])) != MC_OK) { free_batches(g); return rc; }
+        e = hipMalloc((void **)&g->d_slab[m], per_slot * 2);
+        if (e != hipSuccess) return oom("device batch buffers", e);
         for (int si = 0; si < 2; si++) {
             GSlot &s = g->slots[(size_t)m * 2 + si];
-            hipError_t e = hipMalloc(&s.d_ptr, (max_reads + 1) * 4);
-            if (e == hipSuccess) e = hipMalloc(&s.d_con, max_con * 2);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_query, hipEventDisableTiming);
-            if (shards) {
-                if (e == hipSuccess) e = hipMalloc(&s.d_rows, max_reads * row_len * 2);
-                if (e == hipSuccess) e = hipMalloc(&s.d_recv, (size_t)(n > 1 ? n - 1 : 1) * g->per * row_len * 2);
-                if (e == hipSuccess) e = hipMalloc(&s.d_final, g->per * MC_FINAL_ROW * 2);
-                if (e == hipSuccess && g->want_rows) e = hipMalloc(&s.d_merged, g->per * row_len * 2);
-            } else {
-                if (e == hipSuccess) e = hipMalloc(&s.d_final, max_reads * MC_FINAL_ROW * 2);
-                if (e == hipSuccess && g->want_rows) e = hipMalloc(&s.d_rows, max_reads * row_len * 2);
-            }
-            if (e != hipSuccess) return oom("device batch buffers", e);
+            uint8_t *base = g->d_slab[m] + per_slot * si;
+            s.d_ptr = (uint32_t *)base;
+            s.d_con = (uint16_t *)(base + d_ptr);
+            s.d_rows = d_rows ? (uint16_t *)(base + d_ptr + d_con) : nullptr;
+            s.d_recv = d_recv ? (uint16_t *)(base + d_ptr + d_con + d_rows) : nullptr;
+            s.d_final = (uint16_t *)(base + d_ptr + d_con + d_rows + d_recv);
+            s.d_merged = d_mrg ? (uint16_t *)(base + d_ptr + d_con + d_rows + d_recv + d_fin) : nullptr;
+            e = hipEventCreateWithFlags(&s.ev_query, hipEventDisableTiming);
+            if (e != hipSuccess) return oom("events", e);
         }
     }
     return MC_OK;

@@ -27,10 +27,15 @@
 #include <sys/time.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #ifdef _OPENMP
@@ -68,6 +73,48 @@ void mc_check(int rc, const char *what)
 {
     if (rc != MC_OK) die(std::string(what) + ": " + mc_last_error());
 }
+
+// worker threads with one FIFO of tasks
+class Pool {
+public:
+    explicit Pool(int n)
+    {
+        for (int i = 0; i < n; i++) th_.emplace_back([this]() { loop(); });
+    }
+    ~Pool() { finish(); }
+    void run(std::function<void()> f)
+    {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); }
+        cv_.notify_one();
+    }
+    void finish()          // runs what is queued, then joins
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) if (t.joinable()) t.join();
+        th_.clear();
+    }
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this]() { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
 
 struct Options {
     size_t k = 31, cpu = 1, gap = 0, batches = 1, devices = 0;
@@ -187,47 +234,63 @@ struct Classifier {
         std::vector<size_t> first(nbatch + 1);
         for (size_t b = 0; b <= nbatch; b++) first[b] = n_objects * b / nbatch;
         size_t max_reads = 1, max_con = 8;
-        for (size_t b = 0; b < nbatch; b++) {
-            max_reads = std::max(max_reads, first[b + 1] - first[b]);
-            max_con = std::max(max_con, container_bound(R, first[b], first[b + 1], (unsigned)opt.k));
+        {
+            std::vector<size_t> bound(nbatch, 0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+            for (long b = 0; b < (long)nbatch; b++) bound[b] = container_bound(R, first[b], first[b + 1], (unsigned)opt.k);
+            for (size_t b = 0; b < nbatch; b++) {
+                max_reads = std::max(max_reads, first[b + 1] - first[b]);
+                max_con = std::max(max_con, bound[b]);
+            }
         }
         if (max_con > 0xFFFFFFFFull) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).", -1);
 
-        mc_check(mc_group_alloc_batches(grp, (uint32_t)nbatch, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
+        // The reference pins buffers for ALL batches of a file at once (CuClarkDB::malloc, CuClarkDB.cu:321-421).
+        // Pinning costs ~0.3 ms per MB, so the batches go through a ring of a few buffer sets instead: batch b
+        // uses set b % nbuf and is packed once batch b - nbuf has been formatted.
+        const size_t nbuf = opt.dump ? nbatch : std::min(nbatch, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
+        mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
 
         const uint32_t flags = MC_F_FINAL | (opt.ext ? MC_F_ROWS : 0);
         std::vector<size_t> ncon(nbatch, 0);
-        FILE *dump = opt.dump ? std::fopen(opt.dump, "wb") : nullptr;
-#ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic)
-#endif
-        for (long b = 0; b < (long)nbatch; b++) {
-            uint32_t *ptr; uint16_t *con;
-            mc_check(mc_group_batch_buffers(grp, (uint32_t)b, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
-            ncon[b] = pack_reads(map, R, first[b], first[b + 1], (unsigned)opt.k, ptr, con);
-#ifdef _OPENMP
-#pragma omp critical(submit)
-#endif
-            {
-                mc_check(mc_group_submit(grp, (uint32_t)b, first[b + 1] - first[b], ncon[b], flags), "mc_group_submit");
-            }
-        }
-        if (dump) {
-            for (size_t b = 0; b < nbatch; b++) {
-                uint32_t *ptr; uint16_t *con;
-                mc_group_batch_buffers(grp, (uint32_t)b, &ptr, &con, nullptr, nullptr);
-                const uint64_t n = first[b + 1] - first[b], c = ncon[b];
-                std::fwrite(&n, 8, 1, dump); std::fwrite(&c, 8, 1, dump);
-                std::fwrite(ptr, 4, n + 1, dump); std::fwrite(con, 2, c, dump);
-            }
-            std::fclose(dump);
-        }
-
         const double ts2 = now();
+
+        // One pool of worker threads runs two kinds of tasks: PACK (2-bit pack a batch into its pinned buffers,
+        // then submit it: H2D, kernel, D2H are asynchronous) and FORMAT (one slice of a finished batch's CSV
+        // lines).  The main thread waits for the batches in order, hands their slices to the pool and writes
+        // them out -- so packing, the GPU, formatting and writing overlap instead of running as three phases
+        // (the reference serialises queryBatch behind an omp critical and prints on one thread,
+        // src/CuCLARK_hh.hh:1737-1741, :2073-2121).
+        Pool pool((int)std::max<size_t>(1, opt.cpu));
+        std::mutex submit_mu, done_mu;
+        std::condition_variable done_cv;
+        std::vector<char> submitted(nbatch, 0);
+        auto enqueue_pack = [&](size_t b) {
+            pool.run([&, b]() {
+                const uint32_t buf = (uint32_t)(b % nbuf);
+                uint32_t *ptr; uint16_t *con;
+                mc_check(mc_group_batch_buffers(grp, buf, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
+                ncon[b] = pack_reads(map, R, first[b], first[b + 1], (unsigned)opt.k, ptr, con);
+                {
+                    std::lock_guard<std::mutex> lk(submit_mu);
+                    mc_check(mc_group_submit(grp, buf, first[b + 1] - first[b], ncon[b], flags), "mc_group_submit");
+                }
+                { std::lock_guard<std::mutex> lk(done_mu); submitted[b] = 1; }
+                done_cv.notify_all();
+            });
+        };
+        for (size_t b = 0; b < nbuf; b++) enqueue_pack(b);
+
         // header (reference :1951-1967)
-        std::fputs("Object_ID", fout);
-        if (opt.ext) for (size_t t = 1; t < T.names.size(); t++) std::fprintf(fout, ",%s", T.names[t].c_str());
-        std::fputs(",Gamma,Assignment,Score,Confidence\n", fout);
+        std::string head = "Object_ID";
+        if (opt.ext) for (size_t t = 1; t < T.names.size(); t++) { head += ","; head += T.names[t]; }
+        head += ",Gamma,Assignment,Score,Confidence\n";
+        std::fwrite(head.data(), 1, head.size(), fout);
+        std::fflush(fout);
+        const int fd = fileno(fout);
+        uint64_t file_off = head.size();             // slices are written with pwrite by the pool, in parallel
         std::cerr << (opt.ext ? "Writing extended results... " : "Writing results... ") << std::endl;
 
         const size_t row_len = 2 * (size_t)MAXHITS + 2;
@@ -235,78 +298,126 @@ struct Classifier {
         // a batch's lines are formatted in parallel slices (same printf conversions as the
         // reference, :2115-2118) and written in read order
         const int nfmt = (int)std::max<size_t>(1, opt.cpu);
-        std::vector<std::string> slice(nfmt);
-        std::vector<long> s_min(nfmt), s_max(nfmt), s_sum(nfmt);
-        for (size_t b = 0; b < nbatch; b++) {
-            mc_check(mc_group_wait(grp, (uint32_t)b), "mc_group_wait");
-            uint16_t *fin, *rows;
-            mc_group_batch_buffers(grp, (uint32_t)b, nullptr, nullptr, &fin, &rows);
+        struct Formatted {
+            std::vector<std::string> slice;
+            std::vector<long> s_min, s_max, s_sum;
+            int left = 0;
+        };
+        std::vector<Formatted> fmt(nbatch);
+        auto format_slice = [&](size_t b, int sl, const uint16_t *fin, const uint16_t *rows) {
+            Formatted &F = fmt[b];
             const size_t r0 = first[b], nr = first[b + 1] - first[b];
-#ifdef _OPENMP
-#pragma omp parallel for schedule(static, 1) num_threads(nfmt)
-#endif
-            for (int sl = 0; sl < nfmt; sl++) {
-                std::string &out = slice[sl];
-                out.clear();
-                s_min[sl] = (long)T.names.size() - 1; s_max[sl] = 0; s_sum[sl] = 0;
-                char line[256];
-                std::string cells;
-                for (size_t i = r0 + nr * sl / nfmt; i < r0 + nr * (sl + 1) / nfmt; i++) {
-                    const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
-                    const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
-                    size_t nl = R.name_e[i] - R.name_s[i];
-                    if (nl >= OBJECTNAMEMAX) nl = OBJECTNAMEMAX - 1;
-                    out.append((const char *)map + R.name_s[i], nl);
-                    const uint32_t norm = (uint32_t)(paired ? R.len[i] - NBN : R.len[i]);     // ITYPE objectNorm
-                    const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
-                    double delta = (double)(best + s_best);
-                    delta = (delta < 0.001) ? 0 : ((double)best) / delta;
-                    const char *assign = ibest < T.names.size() ? T.names[ibest].c_str() : "NA";
-                    if (opt.ext) {
-                        // all scores, zeros for the targets not hit (reference :2006-2026)
-                        const uint16_t *row = rows + (i - r0) * row_len;
-                        cells.clear();
-                        size_t w = 0;
-                        for (uint32_t h = 0; h < row[0]; h++) {
-                            const size_t t = row[1 + 2 * h];
-                            for (; w < t; w++) cells += ",0";
-                            cells += ","; cells += std::to_string(row[2 + 2 * h]);
-                            w++;
-                        }
-                        for (; w < T.names.size() - 1; w++) cells += ",0";
-                        out += cells;
-                        s_max[sl] = std::max<long>(s_max[sl], row[0]); s_min[sl] = std::min<long>(s_min[sl], row[0]); s_sum[sl] += row[0];
+            std::string &out = F.slice[sl];
+            out.clear();
+            out.reserve((nr / nfmt + 1) * 48);
+            F.s_min[sl] = (long)T.names.size() - 1; F.s_max[sl] = 0; F.s_sum[sl] = 0;
+            char line[256];
+            std::string cells;
+            for (size_t i = r0 + nr * sl / nfmt; i < r0 + nr * (sl + 1) / nfmt; i++) {
+                const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
+                const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
+                size_t nl = R.name_e[i] - R.name_s[i];
+                if (nl >= OBJECTNAMEMAX) nl = OBJECTNAMEMAX - 1;
+                out.append((const char *)map + R.name_s[i], nl);
+                const uint32_t norm = (uint32_t)(paired ? R.len[i] - NBN : R.len[i]);     // ITYPE objectNorm
+                const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
+                double delta = (double)(best + s_best);
+                delta = (delta < 0.001) ? 0 : ((double)best) / delta;
+                const char *assign = ibest < T.names.size() ? T.names[ibest].c_str() : "NA";
+                if (opt.ext) {
+                    // all scores, zeros for the targets not hit (reference :2006-2026)
+                    const uint16_t *row = rows + (i - r0) * row_len;
+                    cells.clear();
+                    size_t w = 0;
+                    for (uint32_t h = 0; h < row[0]; h++) {
+                        const size_t t = row[1 + 2 * h];
+                        for (; w < t; w++) cells += ",0";
+                        cells += ","; cells += std::to_string(row[2 + 2 * h]);
+                        w++;
                     }
-                    // ",%g," gamma, assignment, ",%u,%g\n" best, confidence -- the two ratios without printf
-                    // where format.hpp covers them (it declines the odd cases: reads shorter than k, ties)
-                    char *o = line;
-                    *o++ = ',';
-                    const int64_t den = (int64_t)norm - (int64_t)opt.k + 1;
-                    int m = den > 0 ? fmt_ratio_g(o, total, (uint64_t)den) : 0;
-                    if (!m) m = std::snprintf(o, 64, "%g", gamma);
-                    o += m;
-                    *o++ = ',';
-                    out.append(line, (size_t)(o - line));
-                    out += assign;
-                    o = line;
-                    *o++ = ',';
-                    o += fmt_u32(o, best);
-                    *o++ = ',';
-                    m = fmt_ratio_g(o, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
-                    if (!m) m = std::snprintf(o, 64, "%g", delta);
-                    o += m;
-                    *o++ = '\n';
-                    out.append(line, (size_t)(o - line));
+                    for (; w < T.names.size() - 1; w++) cells += ",0";
+                    out += cells;
+                    F.s_max[sl] = std::max<long>(F.s_max[sl], row[0]); F.s_min[sl] = std::min<long>(F.s_min[sl], row[0]); F.s_sum[sl] += row[0];
                 }
+                // ",%g," gamma, assignment, ",%u,%g\n" best, confidence -- the two ratios without printf
+                // where format.hpp covers them (it declines the odd cases: reads shorter than k, ties)
+                char *o = line;
+                *o++ = ',';
+                const int64_t den = (int64_t)norm - (int64_t)opt.k + 1;
+                int m = den > 0 ? fmt_ratio_g(o, total, (uint64_t)den) : 0;
+                if (!m) m = std::snprintf(o, 64, "%g", gamma);
+                o += m;
+                *o++ = ',';
+                out.append(line, (size_t)(o - line));
+                out += assign;
+                o = line;
+                *o++ = ',';
+                o += fmt_u32(o, best);
+                *o++ = ',';
+                m = fmt_ratio_g(o, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
+                if (!m) m = std::snprintf(o, 64, "%g", delta);
+                o += m;
+                *o++ = '\n';
+                out.append(line, (size_t)(o - line));
             }
+        };
+        // results of batch b are on the host -> its slices go to the pool
+        auto launch_format = [&](size_t b) {
+            { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return submitted[b] != 0; }); }
+            mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
+            uint16_t *fin, *rows;
+            mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, &fin, &rows);
+            Formatted &F = fmt[b];
+            F.slice.assign(nfmt, std::string()); F.s_min.assign(nfmt, 0); F.s_max.assign(nfmt, 0); F.s_sum.assign(nfmt, 0);
+            F.left = nfmt;
+            for (int sl = 0; sl < nfmt; sl++)
+                pool.run([&, b, sl, fin, rows]() {
+                    format_slice(b, sl, fin, rows);
+                    { std::lock_guard<std::mutex> lk(done_mu); fmt[b].left--; }
+                    done_cv.notify_all();
+                });
+        };
+        launch_format(0);
+        for (size_t b = 0; b < nbatch; b++) {
+            if (b + 1 < nbatch) launch_format(b + 1);           // batch b+1 is formatted while batch b is written
+            { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return fmt[b].left == 0; }); }
+            if (b + nbuf < nbatch) enqueue_pack(b + nbuf);      // this batch's buffers are free again
+            Formatted &F = fmt[b];
+            const size_t nr = first[b + 1] - first[b];
             for (int sl = 0; sl < nfmt; sl++) {
-                std::fwrite(slice[sl].data(), 1, slice[sl].size(), fout);
-                if (opt.ext && nr) { nz_max = std::max(nz_max, s_max[sl]); nz_min = std::min(nz_min, s_min[sl]); nz_sum += s_sum[sl]; }
+                const uint64_t at = file_off;
+                file_off += F.slice[sl].size();
+                if (opt.ext && nr) { nz_max = std::max(nz_max, F.s_max[sl]); nz_min = std::min(nz_min, F.s_min[sl]); nz_sum += F.s_sum[sl]; }
+                if (F.slice[sl].empty()) continue;
+                pool.run([&, b, sl, at]() {
+                    std::string &str = fmt[b].slice[sl];
+                    const char *p = str.data();
+                    size_t left = str.size();
+                    uint64_t off = at;
+                    while (left) {
+                        const ssize_t w = ::pwrite(fd, p, left, (off_t)off);
+                        if (w <= 0) die(std::string("Failed to write ") + csv, -1);
+                        p += w; left -= (size_t)w; off += (uint64_t)w;
+                    }
+                    std::string().swap(str);
+                });
             }
+        }
+        pool.finish();
+        if (opt.dump) {
+            FILE *dump = std::fopen(opt.dump, "wb");
+            for (size_t b = 0; dump && b < nbatch; b++) {           // (nbuf == nbatch when dumping)
+                uint32_t *ptr; uint16_t *con;
+                mc_group_batch_buffers(grp, (uint32_t)b, &ptr, &con, nullptr, nullptr);
+                const uint64_t n = first[b + 1] - first[b], c = ncon[b];
+                std::fwrite(&n, 8, 1, dump); std::fwrite(&c, 8, 1, dump);
+                std::fwrite(ptr, 4, n + 1, dump); std::fwrite(con, 2, c, dump);
+            }
+            if (dump) std::fclose(dump);
         }
         std::fclose(fout);
         if (opt.verbose)
-            std::cerr << "timing: index " << ts1 - ts0 << " s, alloc+pack+submit " << ts2 - ts1 << " s, wait+format+write "
+            std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "
                       << now() - ts2 << " s\n";
         std::cerr << "Done." << std::endl;
         if (opt.ext && n_objects)

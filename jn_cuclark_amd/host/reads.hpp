@@ -11,18 +11,47 @@
 #pragma once
 
 #include "common.hpp"
+#include "simd.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <string>
 #include <vector>
 
 namespace host {
 
+// a growable u64 array that never zero-fills: resizing the five columns of a 2 M-read index through
+// std::vector cost a serial 80 MB memset plus its page faults -- a third of the whole run
+class Column {
+public:
+    Column() = default;
+    Column(const Column &) = delete;
+    Column &operator=(const Column &) = delete;
+    Column(Column &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    ~Column() { std::free(p_); }
+    size_t size() const { return n_; }
+    uint64_t &operator[](size_t i) { return p_[i]; }
+    const uint64_t &operator[](size_t i) const { return p_[i]; }
+    void reserve(size_t c)
+    {
+        if (c <= cap_) return;
+        void *q = std::realloc(p_, c * sizeof(uint64_t));
+        if (!q) throw std::bad_alloc();
+        p_ = static_cast<uint64_t *>(q); cap_ = c;
+    }
+    void push_back(uint64_t v) { if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024); p_[n_++] = v; }
+    void resize(size_t n) { reserve(n); n_ = n; }          // new elements are NOT initialised
+private:
+    uint64_t *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 struct ReadIndex {
-    std::vector<uint64_t> name_s, name_e;   // object name = bytes [name_s, name_e)
-    std::vector<uint64_t> spos, epos;       // sequence bytes [spos, epos) (may span lines)
-    std::vector<uint64_t> len;              // bases, newlines not counted
+    Column name_s, name_e;   // object name = bytes [name_s, name_e)
+    Column spos, epos;       // sequence bytes [spos, epos) (may span lines)
+    Column len;              // bases, newlines not counted
     size_t size() const { return len.size(); }
 };
 
@@ -31,22 +60,27 @@ inline bool is_sep(uint8_t c) { return c == ' ' || c == '\t' || c == '\n'; }
 // One pass over the file image.  Record rules as in the reference
 // (src/CuCLARK_hh.hh:1340-1404 FASTA, :1476-1533 FASTQ): the name ends at the first
 // space/tab/newline; a FASTA sequence runs to the next '>' ; FASTQ records are 4 lines.
-inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &err)
+template <typename Scan>
+inline bool index_reads_with(const uint8_t *t, size_t nb, ReadIndex &R, std::string &err)
 {
     if (nb == 0) { err = "empty file"; return false; }
+    Scan nl(t, nb);
+    {   // most records are a few hundred bytes: fewer reallocations of the five arrays
+        const size_t guess = nb / 200 + 16;
+        R.name_s.reserve(guess); R.name_e.reserve(guess); R.spos.reserve(guess); R.epos.reserve(guess); R.len.reserve(guess);
+    }
     if (t[0] == '>') {
         size_t i = 1;
         while (true) {
             R.name_s.push_back(i);
             while (i < nb && !is_sep(t[++i])) {}      // as the reference: the first byte is never a separator
             R.name_e.push_back(i);
-            while (i < nb && t[i] != '\n') i++;
+            i = nl.next(i);
             if (i < nb) i++;
             const size_t s = i;
             size_t e = i, lines = 0;
             while (i < nb && t[i] != '>') {
-                const void *p = std::memchr(t + i, '\n', nb - i);
-                const size_t j = p ? (size_t)((const uint8_t *)p - t) : nb;
+                const size_t j = nl.next(i);
                 lines++;
                 e = j;
                 i = j < nb ? j + 1 : nb;
@@ -66,18 +100,17 @@ inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &
             R.name_s.push_back(i);
             while (i < nb && !is_sep(t[++i])) {}      // as the reference: the first byte is never a separator
             R.name_e.push_back(i);
-            while (i < nb && t[i] != '\n') i++;
+            i = nl.next(i);
             if (i < nb) i++;
             const size_t s = i;
-            const void *p = i < nb ? std::memchr(t + i, '\n', nb - i) : nullptr;
-            const size_t e = p ? (size_t)((const uint8_t *)p - t) : nb;
+            const size_t e = nl.next(i);
             R.spos.push_back(s);
             R.epos.push_back(e);
             R.len.push_back(e - s);
             i = e < nb ? e + 1 : nb;
             for (int l = 0; l < 2; l++) {          // '+' line and quality line
-                const void *q = i < nb ? std::memchr(t + i, '\n', nb - i) : nullptr;
-                i = q ? (size_t)((const uint8_t *)q - t) + 1 : nb;
+                const size_t q = nl.next(i);
+                i = q < nb ? q + 1 : nb;
             }
             if (i + 1 >= nb) break;
             i++;   // past '@'
@@ -86,6 +119,14 @@ inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &
     }
     err = "Failed to recognize the format of the file.";
     return false;
+}
+
+inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &err)
+{
+#ifdef MC_HOST_X86
+    if (cpu_has_avx2()) return index_reads_with<NewlineScanAvx2>(t, nb, R, err);
+#endif
+    return index_reads_with<NewlineScanLibc>(t, nb, R, err);
 }
 
 // Parallel front end of index_reads: the file is cut into `nthreads` byte ranges, every
@@ -139,15 +180,18 @@ inline bool index_reads_parallel(const uint8_t *t, size_t nb, int nthreads, Read
     size_t total = 0;
     for (int p = 0; p < nthreads; p++) { if (!ok[p]) { err = errs[p]; return false; } total += part[p].size(); }
     R.name_s.resize(total); R.name_e.resize(total); R.spos.resize(total); R.epos.resize(total); R.len.resize(total);
-    size_t at = 0;
+    std::vector<size_t> first(nthreads + 1, 0);
+    for (int p = 0; p < nthreads; p++) first[p + 1] = first[p] + part[p].size();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+#endif
     for (int p = 0; p < nthreads; p++) {
-        const size_t n = part[p].size(), off = cut[p];
+        const size_t n = part[p].size(), off = cut[p], at = first[p];
         for (size_t i = 0; i < n; i++) {
             R.name_s[at + i] = part[p].name_s[i] + off; R.name_e[at + i] = part[p].name_e[i] + off;
             R.spos[at + i] = part[p].spos[i] + off;     R.epos[at + i] = part[p].epos[i] + off;
             R.len[at + i] = part[p].len[i];
         }
-        at += n;
     }
     return true;
 }
@@ -184,6 +228,10 @@ inline size_t pack_reads(const uint8_t *t, const ReadIndex &R, size_t r0, size_t
             const size_t slot = count++;      // length slot of this part
             uint32_t plen = 0, cur = 0;
             uint16_t w = 0;
+            {   // whole 32-base blocks of the run, vectorised; the scalar loop takes over at the first other byte
+                const size_t done = pack_blocks(t + i, e - i, con + count);
+                i += done; count += done / 8; plen += (uint32_t)done;
+            }
             while (i < e) {
                 const int code = ct.r[t[i]];
                 if (code < 0) {

@@ -310,9 +310,44 @@ def test_gpu_database_build_is_byte_identical_to_cpu_build(tmp_path, variant):
 
 def _input_harness(tmp_path):
     exe = str(tmp_path / "host_input")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"],
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fopenmp", "-o", exe, os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"],
                    check=True)
     return exe
+
+
+@pytest.mark.parametrize("fmt", ["fastq", "fasta_wide", "fasta_70"])
+def test_indexer_and_vectorised_packer_equal_the_oracle(oracle, tmp_path, fmt):
+    """host/reads.hpp + host/simd.hpp on the CPU: parallel indexer (byte ranges cut at record starts) and the
+    packer whose runs of bases go through 32-base AVX2 blocks -- ragged reads, lower case, U, N runs, reads
+    and parts shorter than k, long reads; against the oracle's restatement of the reference packer
+    (src/CuCLARK_hh.hh:1629-1707)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    exe = _input_harness(tmp_path)
+    k = 27
+    genomes = synth.toy_genomes(4, 9000, seed=77)
+    names, seqs = mixed_fasta(genomes, k, seed=31, n=6000)
+    rng = np.random.default_rng(3)
+    for i in range(0, 6000, 97):                       # long reads: many whole blocks, odd tails
+        L = int(rng.integers(300, 4000))
+        s = bytearray(synth.codes_to_ascii(genomes[i % 4][:L]))
+        if i % 2:
+            s[int(rng.integers(0, L))] = ord("n")
+        seqs[i] = bytes(s)
+    text = (synth.fastq_text(names, seqs) if fmt == "fastq" else
+            synth.fasta_text(names, seqs, width=0 if fmt == "fasta_wide" else 70))
+    f = tmp_path / "reads.txt"
+    f.write_bytes(text)
+    ns, ne, sp, ep, ln = oracle.index_reads(text)
+    rp, con = oracle.pack_reads(text, sp, ep, ln, k)
+    for threads in ("1", "5"):
+        r = subprocess.run([exe, "pack", str(f), str(k), threads], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        n, c = np.frombuffer(r.stdout, dtype=np.uint64, count=2)
+        got_rp = np.frombuffer(r.stdout, dtype=np.uint32, count=int(n) + 1, offset=16)
+        got_con = np.frombuffer(r.stdout, dtype=np.uint16, count=int(c), offset=16 + 4 * (int(n) + 1))
+        assert int(n) == ln.size and np.array_equal(got_rp, rp) and np.array_equal(got_con, con)
 
 
 def test_input_images_gzip_and_pairing(tmp_path):
