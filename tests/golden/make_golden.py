@@ -137,11 +137,98 @@ def config0_targets(tmp):
     print("config0/: targets_rank0.txt, targets_rank1.txt, files_excluded.txt written")
 
 
+def abundance_inputs(d):
+    """a toy NCBI-style taxonomy (two phyla, a species group, a strain below a species, an id the tree does not
+    know) and two per-read result files in the classifier's CSV format"""
+    os.makedirs(os.path.join(d, "db", "taxonomy"), exist_ok=True)
+    nodes = [  # id, parent, rank
+        (1, 1, "no rank"), (131567, 1, "no rank"), (2, 131567, "superkingdom"),
+        (1224, 2, "phylum"), (1236, 1224, "class"), (91347, 1236, "order"), (543, 91347, "family"),
+        (561, 543, "genus"), (562, 561, "species"), (511145, 562, "no rank"),
+        (590, 543, "genus"), (28901, 590, "species"),
+        (1239, 2, "phylum"), (91061, 1239, "class"), (1385, 91061, "order"), (90964, 1385, "family"),
+        (1279, 90964, "genus"), (1280, 1279, "species"),
+        (186817, 1385, "family"), (1386, 186817, "genus"), (653685, 1386, "species group"), (1423, 653685, "species"),
+        (10239, 1, "superkingdom"), (10508, 10239, "family"), (10509, 10508, "genus"), (129951, 10509, "species"),
+    ]
+    names = {1: "root", 131567: "cellular organisms", 2: "Bacteria", 1224: "Proteobacteria", 1236: "Gammaproteobacteria",
+             91347: "Enterobacterales", 543: "Enterobacteriaceae", 561: "Escherichia", 562: "Escherichia coli",
+             511145: "Escherichia coli str. K-12 substr. MG1655", 590: "Salmonella", 28901: "Salmonella enterica",
+             1239: "Firmicutes", 91061: "Bacilli", 1385: "Bacillales", 90964: "Staphylococcaceae", 1279: "Staphylococcus",
+             1280: "Staphylococcus aureus", 186817: "Bacillaceae", 1386: "Bacillus", 653685: "Bacillus subtilis group",
+             1423: "Bacillus subtilis", 10239: "Viruses", 10508: "Adenoviridae", 10509: "Mastadenovirus",
+             129951: "Human mastadenovirus C"}
+    with open(os.path.join(d, "db", "taxonomy", "nodes.dmp"), "w") as f:
+        for i, p_, r in nodes:
+            f.write("%d\t|\t%d\t|\t%s\t|\t\t|\t0\t|\t1\t|\t11\t|\t1\t|\t0\t|\t1\t|\t0\t|\t0\t|\t\t|\n" % (i, p_, r))
+    with open(os.path.join(d, "db", "taxonomy", "names.dmp"), "w") as f:
+        for i in sorted(names):
+            if i == 562:
+                f.write("562\t|\tBacillus coli\t|\t\t|\tsynonym\t|\n")
+            f.write("%d\t|\t%s\t|\t\t|\tscientific name\t|\n" % (i, names[i]))
+    rng = np.random.default_rng(3)
+    labels = ["562", "562", "562", "1280", "1423", "28901", "129951", "511145", "999999", "NA"]
+    for fi, n in ((1, 400), (2, 150)):
+        with open(os.path.join(d, "result%d.csv" % fi), "w") as f:
+            f.write("Object_ID,Gamma,Assignment,Score,Confidence\n")
+            for i in range(n):
+                lab = labels[int(rng.integers(0, len(labels)))]
+                gamma = float(rng.choice([0.0, 0.01, 0.02, 0.05, 0.3, 0.85]))
+                best = int(rng.integers(1, 120))
+                second = int(rng.choice([0, 0, 1, best // 3, best]))
+                conf = best / (best + second)
+                if lab == "NA":
+                    f.write("read%d_%d,0,NA,0,0\n" % (fi, i))
+                else:
+                    f.write("read%d_%d,%g,%s,%d,%g\n" % (fi, i, gamma, lab, best, conf))
+    with open(os.path.join(d, "result_ext.csv"), "w") as f:                    # --extended layout: per-target columns
+        f.write("Object_ID,562,1280,1423,Gamma,Assignment,Score,Confidence\n")
+        for i in range(60):
+            lab = ["562", "1280", "1423", "NA"][i % 4]
+            f.write("x%d,%d,%d,%d,%g,%s,%d,%g\n" % (i, i % 7, i % 5, i % 3, 0.5 if lab != "NA" else 0, lab, 9 if lab != "NA" else 0,
+                                                 0.9 if i % 3 else 0.6))
+
+
+def abundance_golden(tmp):
+    """BASELINE's consumers of the CSV: what the reference's getAbundance (src/getAbundance.cc) and
+    kent -m / -r (app/kent.cpp:605-820) write for the inputs above.  Inputs and the reference's outputs are
+    stored under tests/golden/abundance/."""
+    d = os.path.join(OUT, "abundance")
+    os.makedirs(d, exist_ok=True)
+    abundance_inputs(d)
+    ga, kent = os.path.join(REF, "ref_getAbundance"), os.path.join(REF, "ref_kent")
+    cases = {
+        "plain": ["-F", "result1.csv"],
+        "two_files": ["-F", "result1.csv", "result2.csv"],
+        "taxonomy": ["-D", "db", "-F", "result1.csv", "result2.csv"],
+        "highconf": ["--highconfidence", "-D", "db", "-F", "result1.csv"],
+        "filters": ["-c", "0.8", "-g", "0.02", "-a", "5", "-D", "db", "-F", "result1.csv", "result2.csv"],
+        "extended": ["-D", "db", "-F", "result_ext.csv"],
+        "exports": ["-D", "db", "-F", "result1.csv", "--krona", "--mpa"],
+    }
+    for name, args in cases.items():
+        r = subprocess.run([ga] + args, cwd=d, check=True, capture_output=True, text=True)
+        open(os.path.join(d, "out_%s.csv" % name), "w").write(r.stdout)
+        if name == "exports":
+            for f in ("results.krn", "results.mpa"):
+                os.replace(os.path.join(d, f), os.path.join(d, "out_" + f))
+    # kent -m / -r work on abundance tables; they write under ./results/
+    os.makedirs(os.path.join(tmp, "results"), exist_ok=True)
+    for a, b, out in (("out_taxonomy.csv", "out_highconf.csv", "merged_lineage.csv"), ("out_plain.csv", "out_two_files.csv", "merged_plain.csv")):
+        subprocess.run([kent, "-m", os.path.join(d, a), os.path.join(d, b), "-o", out], cwd=tmp, check=True, capture_output=True)
+        os.replace(os.path.join(tmp, "results", out), os.path.join(d, out))
+    for src, out in (("out_taxonomy.csv", "report_taxonomy.txt"), ("merged_lineage.csv", "report_merged.txt")):
+        subprocess.run([kent, "-r", os.path.join(d, src)], cwd=tmp, check=True, capture_output=True)
+        os.replace(os.path.join(tmp, "results", "report.txt"), os.path.join(d, out))
+    print("abundance/: %d tables, 2 merges, 2 reports written" % len(cases))
+
+
 def main():
     full = "--full" in sys.argv
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         config0_targets(tmp)
-        if "--config0-only" in sys.argv:
+        abundance_golden(tmp)
+        if "--config0-only" in sys.argv or "--text-only" in sys.argv:
             return
         kmer_vectors(tmp)
         db_fixture(tmp, "light_k27", "ref_ht_light", 27, 57777779, 11)

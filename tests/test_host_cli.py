@@ -199,42 +199,67 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
     assert "Done in" in r.stderr and "reads/min" in r.stderr
 
 
-def test_runs_under_the_reference_classify_script(tmp_path):
-    """drop-in under scripts/classify_metagenome.sh (reference :155-159 execs ../bin/cuCLARK[-l]
-    with .settings + its own arguments).  The script is run from a scratch copy made at
-    test time (it needs a writable .settings next to it); only where /root/reference exists.
-    Without a GPU the run stops where the device is opened, after the database build."""
+STAND_IN_SCRIPT = """#!/bin/sh
+# stand-in for the exec line of the reference's scripts/classify_metagenome.sh (:84-87 prepend the contents of
+# .settings, :155-159 exec ../bin/cuCLARK or, with --light, ../bin/cuCLARK-l with the caller's arguments)
+PARAMS="$(tr '\\n' ' ' < ./.settings)"; EXE=cuCLARK
+for a in "$@"; do case "$a" in --light) EXE=cuCLARK-l;; *) PARAMS="$PARAMS $a";; esac; done
+exec ../bin/$EXE $PARAMS
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front", ["script", "kent_script", "kent_direct"])
+def test_runs_under_the_classify_script_and_kent(oracle, tmp_path, front):
+    """drop-in under scripts/classify_metagenome.sh (reference :155-159 execs ../bin/cuCLARK[-l] with .settings +
+    its own arguments) and under `kent -c` (app/kent.cpp:452-553: cd scripts && ./classify_metagenome.sh ...
+    --light, results under ./results/).  Where /root/reference exists the reference's own script is used (from a
+    scratch copy: it needs a writable .settings next to it); on the GPU box a stand-in for its exec line.
+    kent_direct: our kent without any script (-T/-D)."""
     import shutil
-    ref_script = "/root/reference/scripts/classify_metagenome.sh"
-    if not os.path.exists(ref_script):
-        pytest.skip("reference scripts not present on this machine")
     _build()
+    ref_script = "/root/reference/scripts/classify_metagenome.sh"
     (tmp_path / "scripts").mkdir()
     (tmp_path / "bin").mkdir()
-    shutil.copy(ref_script, str(tmp_path / "scripts" / "classify_metagenome.sh"))
-    for exe in ("cuCLARK", "cuCLARK-l"):
+    (tmp_path / "results").mkdir()
+    if front != "kent_direct":
+        dst = tmp_path / "scripts" / "classify_metagenome.sh"
+        if os.path.exists(ref_script):
+            shutil.copy(ref_script, str(dst))
+        else:
+            dst.write_text(STAND_IN_SCRIPT)
+        os.chmod(str(dst), 0o755)
+    for exe in ("cuCLARK", "cuCLARK-l", "kent", "getAbundance"):
         os.symlink(os.path.join(BIN, exe), str(tmp_path / "bin" / exe))
+    k, ht = 27, 57777779
     genomes = synth.toy_genomes(3, 3000, seed=81)
-    targets = _write_targets(tmp_path, genomes, ["A", "B", "C"], n_mask=False)
+    labels = ["A", "B", "C"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
     dbdir = tmp_path / "custom_0"
     dbdir.mkdir()
     (tmp_path / "scripts" / ".settings").write_text("-T %s\n-D %s/\n" % (targets, dbdir))
+    names = [b"r%d" % i for i in range(200)]
+    seqs = [synth.codes_to_ascii(genomes[i % 3][10 * i:10 * i + 150]) for i in range(200)]
+    text = synth.fasta_text(names, seqs)
     reads = tmp_path / "reads.fa"
-    reads.write_bytes(synth.fasta_text([b"r%d" % i for i in range(20)],
-                                       [synth.codes_to_ascii(genomes[i % 3][10 * i:10 * i + 150]) for i in range(20)]))
+    reads.write_bytes(text)
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "jn_cuclark_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run(["sh", "./classify_metagenome.sh", "-O", str(reads), "-R", str(tmp_path / "out"),
-                        "-n", "2", "-b", "4", "--light"], cwd=str(tmp_path / "scripts"),
-                       capture_output=True, text=True, timeout=600, env=env)
-    base = dbdir / "db_central_k27_t3_s57777779_m0_light_4.tsk"
-    assert os.path.exists(str(base) + ".ky"), r.stderr
-    import torch
-    if torch.cuda.is_available():
-        assert r.returncode == 0, r.stderr
-        assert open(str(tmp_path / "out.csv")).readline().startswith("Object_ID,Gamma,Assignment")
+    if front == "script":
+        r = subprocess.run(["sh", "./classify_metagenome.sh", "-O", str(reads), "-R", str(tmp_path / "results" / "out"),
+                            "-n", "2", "-b", "4", "--light"], cwd=str(tmp_path / "scripts"),
+                           capture_output=True, text=True, timeout=600, env=env)
+    elif front == "kent_script":
+        r = subprocess.run([str(tmp_path / "bin" / "kent"), "-c", "-O", "reads.fa", "-R", "out", "-n", "2", "-b", "4"],
+                           cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
     else:
-        assert "No HIP devices" in r.stderr
-    os.remove(str(base) + ".sz")
+        os.remove(str(tmp_path / "scripts" / ".settings"))
+        r = subprocess.run([os.path.join(BIN, "kent"), "-c", "-O", "reads.fa", "-R", "out", "-n", "2", "-b", "4",
+                            "-T", targets, "-D", str(dbdir)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    base = str(dbdir / ("db_central_k27_t3_s%d_m0_light_4.tsk" % ht))
+    want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels)
+    assert open(str(tmp_path / "results" / "out.csv")).read() == want
+    os.remove(base + ".sz")
 
 
 @pytest.mark.gpu
