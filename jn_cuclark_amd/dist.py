@@ -151,6 +151,43 @@ class ShardedClassifier:
         return full
 
 
+def dense_allreduce_classify(backend, reads_ptr, containers, n_reads, num_targets, group=None):
+    """The combine step as BASELINE words it: per-target hit VECTORS all-reduced (sum) across the parts, top-2 on
+    the sum (SURVEY.md 8e option 2).  Every rank ends with all final rows.  n_reads x num_targets int32 per rank on
+    the wire instead of 64 bytes per read, so this is for small target sets and serves as a cross-check of the
+    sparse reduce-scatter above (tests/test_distributed.py, tests/test_gpu_dist.py); plain torch ops, no kernels
+    of its own.  Exact while no read is over MAXHITS distinct targets (a sparse row cannot say more)."""
+    L = backend.row_len
+    rows = torch.zeros((max(n_reads, 1), L), dtype=torch.int16, device=backend.device)
+    backend.query_rows_into(reads_ptr, containers, 0, n_reads, rows)
+    rows = rows[:n_reads].to(torch.int32) & 0xFFFF
+    dense = torch.zeros((n_reads, num_targets), dtype=torch.int32, device=backend.device)
+    cnt = rows[:, 0]
+    slots = torch.arange((L - 2) // 2, device=backend.device)[None, :]
+    valid = slots < cnt[:, None]
+    tgt = rows[:, 1::2][:, : (L - 2) // 2].to(torch.int64)
+    hit = rows[:, 2::2][:, : (L - 2) // 2]
+    dense.scatter_add_(1, torch.where(valid, tgt, torch.zeros_like(tgt)), torch.where(valid, hit, torch.zeros_like(hit)))
+    if dense.is_cuda and dist.get_backend(group) == "gloo":
+        h = dense.cpu()
+        dist.all_reduce(h, group=group)
+        dense = h.to(backend.device)
+    else:
+        dist.all_reduce(dense, group=group)
+    dense.clamp_(max=65535)                                    # counts saturate (DESIGN.md 7)
+    best, ibest = dense.max(dim=1)                             # first maximum = smallest id (ascending scan, strict '>')
+    rest = dense.clone()
+    rest.scatter_(1, ibest[:, None], -1)
+    second, isecond = rest.max(dim=1)
+    fin = torch.zeros((n_reads, 5), dtype=torch.int32, device=backend.device)
+    fin[:, 0] = dense.sum(dim=1) & 0xFFFF
+    fin[:, 1] = torch.where(best > 0, ibest.to(torch.int32) + 1, torch.zeros_like(best))
+    fin[:, 2] = best
+    fin[:, 3] = torch.where(second > 0, isecond.to(torch.int32) + 1, torch.zeros_like(best))
+    fin[:, 4] = second.clamp(min=0)
+    return fin.to(torch.int16)
+
+
 class _Null:
     def __enter__(self):
         return self

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from jn_cuclark_amd import CuClarkDB                                  # noqa: E402
-from jn_cuclark_amd.dist import ShardedClassifier, HipBackend        # noqa: E402
+from jn_cuclark_amd.dist import ShardedClassifier, HipBackend, dense_allreduce_classify        # noqa: E402
 
 
 def main():
@@ -35,6 +35,8 @@ def main():
         again, ranges = sc.classify(rp, con, n)          # buffers are reused: same answer
         torch.cuda.synchronize()
         assert torch.equal(again, torch.cat([full[lo:hi] for lo, hi in ranges]))
+        dense = dense_allreduce_classify(sc.be, rp, con, n, int(d["targets"]))
+        assert torch.equal(dense, full)
         owned = torch.tensor([info["n_keys_owned"]], dtype=torch.int64)
         dist.all_reduce(owned)
         assert int(owned.item()) == info["n_keys"]

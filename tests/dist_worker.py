@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from jn_cuclark_amd import synth                                    # noqa: E402
-from jn_cuclark_amd.dist import ShardedClassifier, shard_range      # noqa: E402
+from jn_cuclark_amd.dist import ShardedClassifier, shard_range, dense_allreduce_classify      # noqa: E402
 from oracle import pyoracle                                         # noqa: E402
 from helpers import small_db                                        # noqa: E402
 
@@ -50,6 +50,9 @@ def main():
     fin = sc.classify_gathered(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
     part, ranges = sc.classify(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
     assert torch.equal(part, torch.cat([fin[lo:hi] for lo, hi in ranges]))
+    # the dense all-reduce of per-target vectors (BASELINE's wording of the combine) gives the same rows
+    dense = dense_allreduce_classify(sc.be, torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads, 10)
+    assert torch.equal(dense, fin)
     if rank == 0:
         want, _ = odb.classify(K, rp, con, MAXHITS)
         np.savez(out, got=fin.numpy().view(np.uint16), want=want)
