@@ -103,7 +103,7 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     index_abort(c);
     // k-mers per 12-slot line.  Fewer per line = fewer overflowing lines = a faster kernel (genome-shaped table,
     // 5.5e9 k-mers: 4 / 5 / 6 / 8 per line -> 993 / 913 / 828 / 705 Mreads/s at 193 / 161 / 140 / 126 GB), so a table
-    // that is alone on the card takes the room it finds: the sparsest fill in [4, 8] that leaves 16 GB free.
+    // that is alone on the card takes the room it finds: the sparsest fill in [4, 12] that leaves 16 GB free.
     // Parts of one table must agree on the line space and use the default (the group loader picks for all).
     double per_line = c->fill_hint > 0.0 ? c->fill_hint : 6.0;
     if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
@@ -625,7 +625,8 @@ int DbFileStream::pass(const ChunkFn &f)
 // share measured on a genome-shaped table, which overflows more than a random one), build counters
 uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill)
 {
-    const double extra = fill <= 4.0 ? 0.12 : fill <= 5.0 ? 0.17 : fill <= 6.0 ? 0.22 : fill <= 7.0 ? 0.32 : 0.45;
+    const double extra = fill <= 4.0 ? 0.12 : fill <= 5.0 ? 0.17 : fill <= 6.0 ? 0.22 : fill <= 7.0 ? 0.32 : fill <= 8.0 ? 0.45
+                       : fill <= 10.0 ? 0.65 : 0.9;
     const double lines = ((double)n_keys_total / fill + 1024.0) / (double)n_parts;
     return (uint64_t)(lines * 128.0 * (1.0 + extra) + lines * 4.0) + (2ull << 30);
 }
@@ -635,7 +636,10 @@ double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes)
     const uint64_t reserve = 16ull << 30;
     for (double f = 4.0; f < 8.0; f += 0.5)
         if (index_bytes(n_keys_total, n_parts, f) + reserve <= free_bytes) return f;
-    return 8.0;
+    // past 8 the lines are mostly full and the chains long: slower, but the table stays on the card
+    for (double f = 8.0; f < 12.0; f += 1.0)
+        if (index_bytes(n_keys_total, n_parts, f) + reserve <= free_bytes) return f;
+    return 12.0;
 }
 
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode == 1 && mz_eligible(c, n_keys_total); }

@@ -102,7 +102,7 @@ int free_batches(mc_group *g)
 uint64_t bytes_for_table(const mc_ctx *c, uint64_t n_keys, uint64_t nb)
 {
     if (mcint::minimizer_index_possible(c, n_keys)) {
-        double per_line = 8.0;          // the densest fill the loader would fall back to
+        double per_line = 10.0;         // a dense fill the loader would still accept (slower, but no exchange between devices)
         if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
         return mcint::index_bytes(n_keys, 1, per_line);
     }

@@ -38,10 +38,11 @@ static constexpr int MZ_LINE = 128;
 static constexpr int MZ_CAP = 12;
 static constexpr int MZ_EMAX = 3;                                        // extra lines chained to a primary line
 static constexpr uint32_t MZ_CHAIN_CAP = (uint32_t)MZ_CAP * (1 + MZ_EMAX);   // k-mers a line keeps (first + extra lines)
-// dword 30 of a primary line: bits 0-2 = extra lines a lookup scans (0..MZ_EMAX; 7 on a crowded line of which
-// some chain was full: a k-mer of it lives in the chain behind), bits 3-7 = s (2^s chains; 0 unless crowded),
-// bits 16-31 = Bloom word
-static constexpr uint32_t MZ_HDR_EXTRA = 7u;
+// dword 30 of a primary line: bits 0-1 = lines per chain (0..MZ_EMAX), bit 2 = a lookup also scans the chain behind
+// its own (some chain was full when the table was built), bits 3-7 = s: the line has 2^s chains and a k-mer's chain
+// is picked by a hash of the k-mer (0: one chain), bits 16-31 = Bloom word
+static constexpr uint32_t MZ_HDR_LEN = 3u;
+static constexpr uint32_t MZ_HDR_TWO = 4u;
 static constexpr uint32_t MZ_HDR_SEG_SHIFT = 3u, MZ_HDR_SEG_MASK = 31u;
 static constexpr uint32_t MZ_SEG_LOAD = 9u;          // k-mers aimed at per segment of MZ_EMAX * MZ_CAP = 36 slots (P(overflow) ~ 1e-12)
 static constexpr uint64_t MZ_EMPTY = ~0ull;
@@ -229,7 +230,7 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
                             if (*key != MZ_EMPTY) continue;
                             if (atomicCAS(key, (unsigned long long)MZ_EMPTY, (unsigned long long)c) == MZ_EMPTY) {
                                 reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[e % MZ_CAP] = labels[koff + j];
-                                if (e >= MZ_EMAX * MZ_CAP) atomicOr(hdr, 2u * MZ_EMAX);      // 3 | 6 = 7: lookups scan two chains (6 lines; see the query)
+                                if (e >= MZ_EMAX * MZ_CAP) atomicOr(hdr, MZ_HDR_TWO);
                                 placed = true;
                             }
                         }
@@ -249,10 +250,19 @@ __host__ __device__ __forceinline__ uint32_t chain_len_of(uint32_t c)
     const uint32_t ex = (c - 1u) / (uint32_t)MZ_CAP;          // ceil((c - CAP) / CAP)
     return ex > (uint32_t)MZ_EMAX ? (uint32_t)MZ_EMAX : ex;
 }
+// number of one-line chains (log2) of an overflowing, not crowded line: its k-mers beyond the first line go to the
+// chain their hash picks, so a lookup reads ONE extra line instead of walking up to three
+__host__ __device__ __forceinline__ uint32_t small_seg_log_of(uint32_t c)
+{
+    return c <= 2u * (uint32_t)MZ_CAP ? 0u : c <= 3u * (uint32_t)MZ_CAP ? 1u : 2u;
+}
 __host__ __device__ __forceinline__ uint32_t extras_of(uint32_t c)
 {
+    if (c <= (uint32_t)MZ_CAP) return 0u;
     const uint32_t s = seg_log_of(c);
-    return s ? ((1u << s) + 1u) * (uint32_t)MZ_EMAX + 1u : chain_len_of(c);       // one spare chain + the line a 7-line scan may touch
+    if (s) return ((1u << s) + 1u) * (uint32_t)MZ_EMAX;             // crowded: 2^s chains of MZ_EMAX lines + one spare chain
+    const uint32_t t = small_seg_log_of(c);
+    return t ? (1u << t) + 1u : 1u;                                   // 2^t one-line chains + one spare line (>= chain_len_of(c))
 }
 __host__ __device__ __forceinline__ uint32_t spilled_of(uint32_t c) { return c > MZ_CHAIN_CAP ? c - (uint32_t)MZ_CAP : 0u; }
 
@@ -346,28 +356,77 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
                 lab = reinterpret_cast<const uint16_t *>(L + 8 * MZ_CAP)[lane % MZ_CAP];
                 mk = kmer_min_key(key, k, m);
             }
+            // a group = the k-mers of ONE target that share the minimizer: what one read's run asks for (related
+            // genomes share minimizers; their k-mers around it differ and belong to different targets)
             uint32_t gsz = 0;
-            for (uint32_t f = 0; f < n; f++) gsz += (lane_bcast64(mk, f) == mk) ? 1u : 0u;
+            for (uint32_t f = 0; f < n; f++) gsz += (lane_bcast64(mk, f) == mk && lane_bcast(lab, f) == lab) ? 1u : 0u;
             uint32_t rank = 0;                       // entries that come before this one (keys are distinct)
             for (uint32_t f = 0; f < n; f++) {
-                const uint32_t gf = lane_bcast(gsz, f);
+                const uint32_t gf = lane_bcast(gsz, f), lf = lane_bcast(lab, f);
                 const uint64_t mf = lane_bcast64(mk, f), kf = lane_bcast64(key, f);
-                const bool before = gf != gsz ? gf > gsz : (mf != mk ? mf < mk : kf < key);
+                const bool before = gf != gsz ? gf > gsz : (mf != mk ? mf < mk : (lf != lab ? lf < lab : kf < key));
                 rank += before ? 1u : 0u;
             }
+            // Where the entries beyond the first line go.  Up to 12 of them: one extra line.  More: 2 or 4 one-line
+            // chains, an entry in the chain its hash picks (seg_of) or -- that one is full -- in the line behind it,
+            // so that a lookup reads one extra line, rarely two.  If some entry would land further away the line
+            // falls back to one linear chain (read front to back, as all chains were before).
+            const bool over = have && rank >= (uint32_t)MZ_CAP;
+            const uint32_t n_over = n - (uint32_t)MZ_CAP;
+            uint32_t seg_log = small_seg_log_of(n);
+            uint32_t dst_line = over ? (rank - MZ_CAP) / MZ_CAP : 0u, dst_slot = over ? (rank - MZ_CAP) % MZ_CAP : 0u;   // linear
+            uint32_t len = (n_over + MZ_CAP - 1u) / MZ_CAP, two = 0u;
+            uint32_t fill[6] = {0u, 0u, 0u, 0u, 0u, 0u};          // used slots of each extra line (wave-uniform)
+            if (seg_log) {
+                const uint32_t n_seg = 1u << seg_log;
+                const uint32_t home = seg_of(key, seg_log);
+                uint32_t cur = home, hl = 0u, hs = 0u;
+                bool placed = false;
+                for (uint32_t sg = 0; sg <= n_seg; sg++) {
+                    const uint64_t want = __ballot(over && !placed && cur == sg);
+                    const uint32_t pos = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                    if (over && !placed && cur == sg) {
+                        if (pos < (uint32_t)MZ_CAP) { placed = true; hl = sg; hs = pos; }
+                        else cur = sg + 1u;
+                    }
+                    const uint32_t cnt = (uint32_t)__popcll(want);
+                    fill[sg] = cnt < (uint32_t)MZ_CAP ? cnt : (uint32_t)MZ_CAP;
+                }
+                const bool bad = __ballot(over && (!placed || hl > home + 1u)) != 0;
+                if (!bad) {
+                    dst_line = hl; dst_slot = hs;
+                    len = 1u;
+                    two = __ballot(over && hl == home + 1u) ? MZ_HDR_TWO : 0u;
+                } else {
+                    seg_log = 0u;
+                }
+            }
+            if (!seg_log)
+                for (uint32_t e = 0; e < 6u; e++) {
+                    const uint32_t used = n_over > e * MZ_CAP ? n_over - e * MZ_CAP : 0u;
+                    fill[e] = used < (uint32_t)MZ_CAP ? used : (uint32_t)MZ_CAP;
+                }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // every entry is in registers before any is rewritten
             __builtin_amdgcn_wave_barrier();
             uint32_t bloom = 0;
             if (have) {
-                uint8_t *L = slot_line(rank);
-                reinterpret_cast<uint64_t *>(L)[rank % MZ_CAP] = key;
-                reinterpret_cast<uint16_t *>(L + 8 * MZ_CAP)[rank % MZ_CAP] = (uint16_t)lab;
-                if (rank >= (uint32_t)MZ_CAP) bloom = extra_mask(key);
+                uint8_t *L = over ? more + (uint64_t)dst_line * MZ_LINE : first;
+                const uint32_t sl = over ? dst_slot : rank;
+                reinterpret_cast<uint64_t *>(L)[sl] = key;
+                reinterpret_cast<uint16_t *>(L + 8 * MZ_CAP)[sl] = (uint16_t)lab;
+                if (over) bloom = extra_mask(key);
+            }
+            // slots of the extra lines that hold nothing (the placing pass wrote entries in arrival order there)
+            const uint32_t n_alloc = extras_of(n);
+            for (uint32_t idx = lane; idx < n_alloc * (uint32_t)MZ_CAP; idx += 64u) {
+                const uint32_t e = idx / MZ_CAP, sl = idx % MZ_CAP;
+                const uint32_t used = e == 0 ? fill[0] : e == 1 ? fill[1] : e == 2 ? fill[2] : e == 3 ? fill[3] : e == 4 ? fill[4] : fill[5];
+                if (sl >= used) reinterpret_cast<uint64_t *>(more + (uint64_t)e * MZ_LINE)[sl] = MZ_EMPTY;
             }
             for (int o = 32; o > 0; o >>= 1) bloom |= (uint32_t)__shfl_xor((int)bloom, o, 64);
             if (lane == 0) {
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
-                hdr[0] = (hdr[0] & 0xFFFFu) | bloom;            // extra_mask() sits in the high half
+                hdr[0] = len | two | (seg_log << MZ_HDR_SEG_SHIFT) | bloom;      // extra_mask() sits in the high half
             }
         }
     }
@@ -719,11 +778,12 @@ void mz_query_kernel(const MzArgs A)
                                 // rare: lines beyond the first (Bloom bits are set only where extra lines exist)
                                 const uint32_t xm = extra_mask(c[s]);
                                 if (!hit[s] && (hdr & xm) == xm) {
-                                    // the chain of this line -- of a crowded line: the one of its 2^s chains this
-                                    // k-mer hashes to (s = 0 otherwise), and the one behind it when bit 8 says that
-                                    // some chain was full
-                                    const uint32_t extra = hdr & MZ_HDR_EXTRA;       // 7 = two chains of a crowded line (+ 1 line: harmless)
-                                    eb += seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * MZ_EMAX;
+                                    // this k-mer's chain of the line: the one of its 2^s chains the k-mer hashes to
+                                    // (s = 0: the only one), and the one behind it when bit 2 says that some chain
+                                    // was full
+                                    const uint32_t len = hdr & MZ_HDR_LEN;
+                                    const uint32_t extra = len << ((hdr >> 2) & 1u);
+                                    eb += seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * len;
                                     for (uint32_t e = 0; e < extra && !hit[s]; e++) {
                                         const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
                                         u32x4 xv[MZ_CAP / 2];
