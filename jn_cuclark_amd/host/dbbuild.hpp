@@ -84,15 +84,18 @@ inline std::string db_name(const std::string &folder, unsigned k, size_t n_label
     return buf;
 }
 
-struct Occ { uint64_t r, q; uint16_t t; };
+struct Occ { uint64_t r, q; uint16_t t; uint32_t w; };      // w: occurrences this entry stands for (spectrum lines carry a count)
 
-// Forward k-mers of one target file, handed to emit(uint64_t).  FASTA: every window of k
+// Forward k-mers of one target file, handed to emit(uint64_t kmer, uint32_t count).  FASTA: every window of k
 // valid bases (full variant, :1127-1180), or -- light variant -- consecutive
 // NON-overlapping windows of which every gap-th is kept (:707-760).  Any non-ACGTU byte
 // except '\n' resets the window; '>' skips its header line.  FASTQ: the sequence line of
-// each 4-line record.
+// each 4-line record.  Anything else is a k-mer SPECTRUM: lines "<k-mer> <count>" (:861-876 light: every gap-th
+// line whose count exceeds min_count, the line counter restarting at each line taken; :1085-1093 full: every
+// line whose count exceeds min_count).
 template <class Emit>
-inline bool scan_target_file(const std::string &path, unsigned k, unsigned gap, Emit &&emit, uint64_t &nt, std::string &err)
+inline bool scan_target_file(const std::string &path, unsigned k, unsigned gap, unsigned min_count, Emit &&emit, uint64_t &nt,
+                             std::string &err)
 {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) { err = "Failed to open " + path; return false; }
@@ -105,9 +108,34 @@ inline bool scan_target_file(const std::string &path, unsigned k, unsigned gap, 
     std::fclose(f);
     if (buf.empty()) return true;
     const bool fasta = buf[0] == '>', fastq = buf[0] == '@';
-    if (!fasta && !fastq) { err = path + ": spectrum-form targets are not supported by this build"; return false; }
-    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     const auto &ct = codes();
+    if (!fasta && !fastq) {
+        uint8_t counter = 0;                 // an 8-bit counter in the reference too
+        size_t i = 0;
+        const size_t n = buf.size();
+        while (i < n) {
+            size_t e = i;
+            while (e < n && buf[e] != '\n') e++;
+            const std::vector<std::string> el = split_line(std::string((const char *)&buf[i], e - i), 2);
+            i = e + 1;
+            if (el.size() < 2) continue;
+            const unsigned long val = (unsigned long)std::atoi(el[1].c_str());
+            const bool take = LIGHT ? (counter % gap == 0 && val > min_count) : val > min_count;
+            if (take) {
+                uint64_t km = 0;
+                for (char ch : el[0]) {
+                    const int code = ch == 'U' || ch == 'u' ? -1 : ct.r[(unsigned char)ch];
+                    if (code < 0) { err = "Failed to compute k-mer value of " + el[0]; return false; }
+                    km = (km << 2) | (uint64_t)code;
+                }
+                emit(km, (uint32_t)val);
+                if (LIGHT) counter = 0;
+            }
+            if (LIGHT) counter++;
+        }
+        return true;
+    }
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
     uint64_t km = 0, iter = 0;
     unsigned cpt = 0;
     size_t i = 0, n = buf.size();
@@ -122,10 +150,10 @@ inline bool scan_target_file(const std::string &path, unsigned k, unsigned gap, 
             cpt++;
             if (cpt >= k) {
                 if (LIGHT) {
-                    if (iter % gap == 0) emit(km);
+                    if (iter % gap == 0) emit(km, 1u);
                     iter++; km = 0; cpt = 0;
                 } else {
-                    emit(km);
+                    emit(km, 1u);
                     cpt = k;
                 }
             }
@@ -143,12 +171,12 @@ inline bool scan_target_file(const std::string &path, unsigned k, unsigned gap, 
     return true;
 }
 
-inline bool collect_file(const std::string &path, uint16_t target, unsigned k, unsigned gap,
+inline bool collect_file(const std::string &path, uint16_t target, unsigned k, unsigned gap, unsigned min_count,
                          std::vector<Occ> &out, uint64_t &nt, std::string &err)
 {
-    return scan_target_file(path, k, gap, [&](uint64_t x) {
+    return scan_target_file(path, k, gap, min_count, [&](uint64_t x, uint32_t w) {
         const uint64_t c = canonical(x, k);
-        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target});
+        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target, w});
     }, nt, err);
 }
 
@@ -161,7 +189,7 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
     for (size_t t = 0; t < T.files.size(); t++) {
         const auto it = std::find(T.labels.begin(), T.labels.end(), T.files[t].second);
         const uint16_t id = (uint16_t)(it - T.labels.begin());
-        if (!collect_file(T.files[t].first, id, k, gap, occ, nt, err)) return false;
+        if (!collect_file(T.files[t].first, id, k, gap, min_count, occ, nt, err)) return false;
         std::fprintf(stderr, "\r Progress report: (%zu/%zu)    ", t + 1, T.files.size());
     }
     std::fprintf(stderr, "%lu nt read in total.\n", (unsigned long)nt);
@@ -186,9 +214,10 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
         while (i < n && occ[i].r < b1) {
             size_t j = i;
             bool multi = false;
-            while (j < n && occ[j].r == occ[i].r && occ[j].q == occ[i].q) { multi |= occ[j].t != occ[i].t; j++; }
+            uint64_t count = 0;
+            while (j < n && occ[j].r == occ[i].r && occ[j].q == occ[i].q) { multi |= occ[j].t != occ[i].t; count += occ[j].w; j++; }
             distinct++;
-            if (!multi && (j - i) > min_count) {      // multiplicity 1 and count > minCount
+            if (!multi && count > min_count) {        // multiplicity 1 and count > minCount
                 uint8_t &s = szbuf[occ[i].r - b0];
                 if (s == 255) { err = "This table can not be stored on disk: Some bucket list size exceeds 255."; return false; }
                 s++;
@@ -244,7 +273,9 @@ inline bool build_database_gpu(const Targets &T, unsigned k, unsigned gap, unsig
                 }
                 km.clear(); tg.clear();
             };
-            if (!scan_target_file(T.files[t].first, k, gap, [&](uint64_t x) {
+            // (a spectrum line's count is its weight in the count > min_count rule: with min_count = 0, the only
+            // value the scripts use, one occurrence says the same; larger thresholds on spectra need the CPU builder)
+            if (!scan_target_file(T.files[t].first, k, gap, min_count, [&](uint64_t x, uint32_t) {
                     km.push_back(x); tg.push_back(id);
                     if (km.size() >= CHUNK) flush();
                 }, lnt, lerr)) {

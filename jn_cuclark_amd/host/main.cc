@@ -12,7 +12,7 @@
 // (include/mc_group.h): N replicas when the table fits one GPU, N shards with a device-to-device
 // exchange of the per-read rows when it does not -- the reference always shards (:552-559).
 // Differences from the reference, all outside the per-read results:
-//   * --tsk (.ht dumps) and spectrum-form targets are not implemented.
+//   * --tsk (.ht dumps) is not implemented.
 #include "../../include/mc_api.h"
 #include "../../include/mc_group.h"
 #include "common.hpp"

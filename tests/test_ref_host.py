@@ -36,7 +36,7 @@ def _targets(tmp_path, genomes, labels):
     return str(t)
 
 
-@pytest.mark.parametrize("mode", ["fasta_multiline", "fastq_3batches", "paired", "extended"])
+@pytest.mark.parametrize("mode", ["fasta_multiline", "fastq_3batches", "paired", "extended", "spectrum_targets"])
 def test_reference_host_and_our_host_agree_byte_for_byte(tmp_path, mode):
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/ref_host_mc_light not built (needs /root/reference at build time)")
@@ -49,6 +49,20 @@ def test_reference_host_and_our_host_agree_byte_for_byte(tmp_path, mode):
     genomes = synth.toy_genomes(5, 6000, seed=61, shared=700)
     labels = ["Ecoli", "Saureus", "Bsub", "Ecoli", "Paer"]
     targets = _targets(tmp_path, genomes, labels)
+    if mode == "spectrum_targets":
+        # two of the five targets as k-mer spectra ("<k-mer> <count>" per line, CuCLARK_hh.hh:861-876): the k-mers of
+        # the genome in file order with small counts, a few of them repeated
+        lines = open(targets).read().split("\n")[:-1]
+        for i in (1, 4):
+            km = synth.kmers_of(genomes[i], k)
+            rows = []
+            for j, x in enumerate(km[: 4000].tolist()):
+                s_ = "".join("TGCA"[(x >> (2 * (k - 1 - t))) & 3] for t in range(k))
+                rows.append("%s %d" % (s_ if j % 3 else s_.lower(), 1 + j % 4))
+            p_ = tmp_path / ("spectrum%d.txt" % i)
+            p_.write_text("\n".join(rows + rows[:50]) + "\n")
+            lines[i] = "%s\t%s" % (p_, labels[i])
+        open(targets, "w").write("\n".join(lines) + "\n")
     names, seqs = mixed_fasta(genomes, k, seed=17, n=1200)
     names = [n + b" trailing words" for n in names]
     extra = []
