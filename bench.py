@@ -399,12 +399,15 @@ def pipelined_rate(db, torch, np, rp_t, con_t, n_reads, fin_expected, nb=4, roun
             db.queryBatch(b)
         for b in range(nb):
             db.waitForBatch(b)
+        # steady state: a batch is resubmitted as soon as its previous results were waited for (no drain per round)
         t0 = time.perf_counter()
-        for _ in range(rounds):
-            for b in range(nb):
-                db.queryBatch(b)
-            for b in range(nb):
+        for i in range(rounds * nb):
+            b = i % nb
+            if i >= nb:
                 db.waitForBatch(b)
+            db.queryBatch(b)
+        for b in range(nb):
+            db.waitForBatch(b)
         dt = time.perf_counter() - t0
         ok = all(np.array_equal(fin_l[b][: per * 5].reshape(per, 5), fin_expected[per * b: per * (b + 1)]) for b in range(nb))
         db.freeBatchMemory()
@@ -415,8 +418,8 @@ def pipelined_rate(db, torch, np, rp_t, con_t, n_reads, fin_expected, nb=4, roun
     return {"value": round(rounds * nb * per / dt / 1e6, 2), "unit": "Mreads/s",
             "h2d_GBs": round(rounds * h2d / dt / 1e9, 2), "d2h_GBs": round(rounds * d2h / dt / 1e9, 2),
             "batches_in_flight": nb, "reads_per_batch": per,
-            "what": "packed reads in pinned host memory -> mc_submit (H2D, kernel, D2H on two streams) -> mc_wait -> final rows "
-                    "in pinned host memory; equal to the device-resident results"}
+            "what": "packed reads in pinned host memory -> mc_submit (H2D, kernel, D2H on three queues chained by events) -> mc_wait "
+                    "-> final rows in pinned host memory; equal to the device-resident results"}
 
 
 def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend):

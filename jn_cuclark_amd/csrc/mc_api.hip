@@ -9,6 +9,7 @@
 
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -34,6 +35,30 @@ int set_dev(mc_ctx *c)
 {
     HIPCHK(hipSetDevice(c->device));
     return MC_OK;
+}
+
+NearDeviceMemory::NearDeviceMemory(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    if (node < 0 || node >= 1024) return;
+    unsigned long mask[16] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    // set_mempolicy(MPOL_PREFERRED = 1, nodemask, maxnode): no libnuma in the image, the raw system call
+    active = syscall(SYS_set_mempolicy, 1, mask, (unsigned long)(sizeof mask * 8)) == 0;
+    if (getenv("MC_DEBUG_NUMA")) fprintf(stderr, "libmcclark: device %d (%s) on NUMA node %d, policy %s\n", device, bus, node, active ? "set" : "refused");
+}
+
+NearDeviceMemory::~NearDeviceMemory()
+{
+    if (active) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
 }
 
 } // namespace mcint
@@ -539,6 +564,36 @@ int launch_merge_result(mc_ctx *c, const uint16_t *const *d_srcs, uint32_t n_src
     return MC_OK;
 }
 
+// One batch through the three queues of a context: H2D on s_in, kernel on streams[0], D2H on s_out.  The two device
+// slots alternate by submission; a slot's next H2D waits for its previous kernel, its next kernel for its previous
+// D2H.  `done` is recorded behind the D2H.
+int submit_batch(mc_ctx *c, const uint32_t *h_ptr, const uint16_t *h_con, uint16_t *h_final, uint16_t *h_rows,
+                 uint64_t n_reads, uint64_t n_con, uint32_t flags, hipEvent_t done)
+{
+    const int si = (int)(c->n_submitted++ & 1u);
+    Slot &s = c->slots[si];
+    const size_t row_len = 2 * (size_t)c->maxhits + 2;
+    if (n_reads) {
+        HIPCHK(hipStreamWaitEvent(c->s_in, c->ev_k[si], 0));
+        HIPCHK(hipMemcpyAsync(s.d_ptr, h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, c->s_in));
+        if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, h_con, n_con * 2, hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(hipEventRecord(c->ev_in[si], c->s_in));
+        HIPCHK(hipStreamWaitEvent(c->streams[0], c->ev_in[si], 0));
+        HIPCHK(hipStreamWaitEvent(c->streams[0], c->ev_out[si], 0));
+        const int rc = launch_query(c, s.d_ptr, s.d_con, n_reads, n_con, flags, s.d_final, s.d_rows, c->streams[0]);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_k[si], c->streams[0]));
+        HIPCHK(hipStreamWaitEvent(c->s_out, c->ev_k[si], 0));
+        if (flags & MC_F_FINAL)
+            HIPCHK(hipMemcpyAsync(h_final, s.d_final, n_reads * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, c->s_out));
+        if (flags & MC_F_ROWS)
+            HIPCHK(hipMemcpyAsync(h_rows, s.d_rows, n_reads * row_len * 2, hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(hipEventRecord(c->ev_out[si], c->s_out));
+    }
+    HIPCHK(hipEventRecord(done, c->s_out));
+    return MC_OK;
+}
+
 // ---- database files, streamed in bucket order ------------------------------------
 namespace {
 bool pread_all(int fd, void *dst, size_t n, uint64_t off)
@@ -729,6 +784,13 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount; }
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc(&c->d_over, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_over, 0, sizeof(unsigned long long));
     if (e != hipSuccess) { delete c; return fail(MC_EHIP, std::string("mc_open: ") + hipGetErrorString(e)); }
@@ -746,6 +808,13 @@ int mc_close(mc_ctx *c)
     index_abort(c);
     if (c->d_over) (void)hipFree(c->d_over);
     for (int i = 0; i < 2; i++) if (c->streams[i]) (void)hipStreamDestroy(c->streams[i]);
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+    }
     delete c;
     return MC_OK;
 }
@@ -931,11 +1000,13 @@ int mc_alloc_batches(mc_ctx *c, uint32_t n_batches, uint64_t max_reads, uint64_t
     c->max_reads = max_reads; c->max_con = max_con; c->want_rows = want_rows != 0;
     const size_t row_len = 2 * (size_t)c->maxhits + 2;
     c->batches.resize(n_batches);
+    mcint::NearDeviceMemory near(c->device);             // the pinned pages go to the GPU's NUMA node
+    const unsigned hflags = near.active ? hipHostMallocNumaUser : hipHostMallocDefault;
     for (auto &b : c->batches) {
-        hipError_t e = hipHostMalloc((void **)&b.h_ptr, (max_reads + 1) * 4, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_con, max_con * 2, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_final, max_reads * MC_FINAL_ROW * 2, hipHostMallocDefault);
-        if (e == hipSuccess && c->want_rows) e = hipHostMalloc((void **)&b.h_rows, max_reads * row_len * 2, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&b.h_ptr, (max_reads + 1) * 4, hflags);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_con, max_con * 2, hflags);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_final, max_reads * MC_FINAL_ROW * 2, hflags);
+        if (e == hipSuccess && c->want_rows) e = hipHostMalloc((void **)&b.h_rows, max_reads * row_len * 2, hflags);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
             mc_free_batches(c);
@@ -979,21 +1050,8 @@ int mc_submit(mc_ctx *c, uint32_t batch, uint64_t n_reads, uint64_t n_con, uint3
     int rc = set_dev(c); if (rc) return rc;
     Batch &b = c->batches[batch];
     if (n_reads && b.h_ptr[n_reads] != n_con) return fail(MC_EINVAL, "reads_ptr[n_reads] != n_containers");
-    const int si = (int)(batch & 1u);
-    Slot &s = c->slots[si];
-    hipStream_t st = c->streams[si];
-    const size_t row_len = 2 * (size_t)c->maxhits + 2;
-    if (n_reads) {
-        HIPCHK(hipMemcpyAsync(s.d_ptr, b.h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
-        if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, b.h_con, n_con * 2, hipMemcpyHostToDevice, st));
-        rc = launch_query(c, s.d_ptr, s.d_con, n_reads, n_con, flags, s.d_final, s.d_rows, st);
-        if (rc) return rc;
-        if (flags & MC_F_FINAL)
-            HIPCHK(hipMemcpyAsync(b.h_final, s.d_final, n_reads * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, st));
-        if (flags & MC_F_ROWS)
-            HIPCHK(hipMemcpyAsync(b.h_rows, s.d_rows, n_reads * row_len * 2, hipMemcpyDeviceToHost, st));
-    }
-    HIPCHK(hipEventRecord(b.ev, st));
+    rc = mcint::submit_batch(c, b.h_ptr, b.h_con, b.h_final, b.h_rows, n_reads, n_con, flags, b.ev);
+    if (rc) return rc;
     b.submitted = true;
     return MC_OK;
 }

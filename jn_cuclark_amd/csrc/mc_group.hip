@@ -92,8 +92,10 @@ int free_batches(mc_group *g)
         if (s.ev_query) (void)hipEventDestroy(s.ev_query);
     }
     g->slots.clear();
-    for (size_t m = 0; m < g->d_slab.size(); m++)
+    for (size_t m = 0; m < g->d_slab.size(); m++) {
+        for (auto &cs : g->ctx[m]->slots) cs = mcint::Slot();           // lent in replica mode: the slab owns them
         if (g->d_slab[m]) { (void)hipSetDevice(g->ctx[m]->device); (void)hipFree(g->d_slab[m]); }
+    }
     g->d_slab.clear();
     return MC_OK;
 }
@@ -288,8 +290,10 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
     const size_t b_ptr = up((max_reads + 1) * 4), b_con = up(max_con * 2), b_fin = up(max_reads * MC_FINAL_ROW * 2),
                  b_rows = g->want_rows ? up(max_reads * row_len * 2) : 0;
     const size_t per_batch = b_ptr + b_con + b_fin + b_rows;
-    // portable: every device of the group copies from / into these
-    hipError_t e = hipHostMalloc((void **)&g->h_slab, per_batch * n_batches, hipHostMallocPortable);
+    // portable: every device of the group copies from / into these; on the NUMA node of the first device
+    mcint::NearDeviceMemory near(g->ctx[0]->device);
+    hipError_t e = hipHostMalloc((void **)&g->h_slab, per_batch * n_batches,
+                                 hipHostMallocPortable | (near.active ? hipHostMallocNumaUser : 0u));
     if (e != hipSuccess) return oom("pinned batch buffers", e);
     g->batches.resize(n_batches);
     for (uint32_t i = 0; i < n_batches; i++) {
@@ -329,6 +333,10 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
             s.d_merged = d_mrg ? (uint16_t *)(base + d_ptr + d_con + d_rows + d_recv + d_fin) : nullptr;
             e = hipEventCreateWithFlags(&s.ev_query, hipEventDisableTiming);
             if (e != hipSuccess) return oom("events", e);
+            if (!shards) {          // replicas run through the member's own batch queues: lend it the buffers
+                mcint::Slot &cs = g->ctx[m]->slots[si];
+                cs.d_ptr = s.d_ptr; cs.d_con = s.d_con; cs.d_final = s.d_final; cs.d_rows = s.d_rows;
+            }
         }
     }
     return MC_OK;
@@ -359,26 +367,20 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
     int rc;
 
     if (g->info.mode != MC_GROUP_SHARDS) {
-        // replicas: the batch goes to one member; its two slots alternate
-        const uint32_t m = (uint32_t)(g->n_submitted % n);
-        const int si = (int)((g->n_submitted / n) & 1u);
-        g->n_submitted++;
+        // replicas: the batch goes to one member, through that context's three queues (copy in, compute, copy out)
+        const uint32_t m = (uint32_t)(g->n_submitted++ % n);
+        const int si = 0;
         mc_ctx *c = g->ctx[m];
-        GSlot &s = g->slots[(size_t)m * 2 + si];
-        hipStream_t st = c->streams[si];
+        hipStream_t st = c->s_out;
         if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
-        if (n_reads) {
-            HIPCHK(hipMemcpyAsync(s.d_ptr, b.h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
-            if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, b.h_con, n_con * 2, hipMemcpyHostToDevice, st));
-            rc = mcint::launch_query(c, s.d_ptr, s.d_con, n_reads, n_con, flags, s.d_final, s.d_rows, st);
-            if (rc) return rc;
-            if (flags & MC_F_FINAL) HIPCHK(hipMemcpyAsync(b.h_final, s.d_final, n_reads * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, st));
-            if (flags & MC_F_ROWS) HIPCHK(hipMemcpyAsync(b.h_rows, s.d_rows, n_reads * row_len * 2, hipMemcpyDeviceToHost, st));
-        }
+        rc = mcint::submit_batch(c, b.h_ptr, b.h_con, b.h_final, b.h_rows, n_reads, n_con, flags, b.done[m]);
+        if (rc) return rc;
         for (uint32_t o = 0; o < n; o++) {                 // every member's event is signalled: wait() needs no mode
+            if (o == m) continue;
             if ((rc = mcint::set_dev(g->ctx[o])) != MC_OK) return rc;
-            HIPCHK(hipEventRecord(b.done[o], o == m ? st : g->ctx[o]->streams[si]));
+            HIPCHK(hipEventRecord(b.done[o], g->ctx[o]->streams[1]));
         }
+        (void)st; (void)si;
         b.submitted = true;
         return MC_OK;
     }

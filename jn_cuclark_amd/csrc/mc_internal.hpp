@@ -79,7 +79,13 @@ struct mc_ctx {
     bool wide = false;          // quotients need 64 bits (reference T64 regime: k = 32)
     int n_cu = 0;
 
-    hipStream_t streams[2] = {nullptr, nullptr};
+    hipStream_t streams[2] = {nullptr, nullptr};      // [0]: compute (query kernels of the batch interface, index build); [1]: group shards, slot 1
+    // The batch interface runs three queues (copy in, compute, copy out) chained by events, not one stream per
+    // slot: two streams that each do copy -> kernel -> copy fall into lockstep (both copy, then both compute) and
+    // overlap nothing (measured: 688 Mreads/s at 30 GB/s although the link does 57 GB/s and the kernel 1260).
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};   // per slot
+    uint64_t n_submitted = 0;
 
     // database
     bool db_loaded = false;
@@ -113,9 +119,24 @@ struct mc_ctx {
 namespace mcint {
 
 int set_dev(mc_ctx *c);
+
+// Pinned host buffers belong on the NUMA node the GPU hangs off: measured on the two-socket MI355X host,
+// H2D runs at 57 GB/s from the near node and at 28 GB/s from the far one (D2H 57 either way; tools/h2d_numa.py),
+// and the HIP allocator places the pages wherever the calling thread happens to run.  While an object of this
+// type lives, the calling thread's memory policy prefers the node of `device` (best effort: no node
+// information or no permission = no change).
+struct NearDeviceMemory {
+    explicit NearDeviceMemory(int device);
+    ~NearDeviceMemory();
+    bool active = false;
+};
 // one query launch on `st` (no synchronisation)
 int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads, uint64_t n_con,
                  uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st);
+// one batch of the batch interface: H2D, kernel, D2H on the context's three queues; `done` behind the D2H.  The
+// device buffers are c->slots[], dealt by submission order.
+int submit_batch(mc_ctx *c, const uint32_t *h_ptr, const uint16_t *h_con, uint16_t *h_final, uint16_t *h_rows,
+                 uint64_t n_reads, uint64_t n_con, uint32_t flags, hipEvent_t done);
 // k-way merge of sparse rows (+ top-2) on `st`
 int launch_merge_result(mc_ctx *c, const uint16_t *const *d_srcs, uint32_t n_srcs, uint64_t n_reads,
                         uint16_t *d_out_rows, uint16_t *d_final, hipStream_t st);
