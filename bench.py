@@ -24,6 +24,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the HIP runtime starts (as bin/cuCLARK does): the copy-in / compute / copy-out queues of the streamed path must
+# not share one of the runtime's default 4 hardware queues (csrc/mc_api.hip, mc_open); no effect on the kernel rate
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 READ_LEN = 150

@@ -9,7 +9,6 @@
 
 #include <fcntl.h>
 #include <sys/stat.h>
-#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -37,29 +36,6 @@ int set_dev(mc_ctx *c)
     return MC_OK;
 }
 
-NearDeviceMemory::NearDeviceMemory(int device)
-{
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
-    for (char *p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
-    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
-    FILE *f = std::fopen(path.c_str(), "r");
-    if (!f) return;
-    int node = -1;
-    if (std::fscanf(f, "%d", &node) != 1) node = -1;
-    std::fclose(f);
-    if (node < 0 || node >= 1024) return;
-    unsigned long mask[16] = {0};
-    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    // set_mempolicy(MPOL_PREFERRED = 1, nodemask, maxnode): no libnuma in the image, the raw system call
-    active = syscall(SYS_set_mempolicy, 1, mask, (unsigned long)(sizeof mask * 8)) == 0;
-    if (getenv("MC_DEBUG_NUMA")) fprintf(stderr, "libmcclark: device %d (%s) on NUMA node %d, policy %s\n", device, bus, node, active ? "set" : "refused");
-}
-
-NearDeviceMemory::~NearDeviceMemory()
-{
-    if (active) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
-}
 
 } // namespace mcint
 
@@ -784,6 +760,10 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount; }
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking);
+    // (The runtime multiplexes the streams of a process over GPU_MAX_HW_QUEUES = 4 hardware queues; when two of the
+    // three queues below share one, a barrier packet of one holds the other back and the streamed rate is ~680
+    // instead of ~1000 Mreads/s.  Stream priorities did not separate them (measured); bin/cuCLARK and bench.py set
+    // GPU_MAX_HW_QUEUES=8 before the runtime starts, which does.)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
@@ -1000,8 +980,7 @@ int mc_alloc_batches(mc_ctx *c, uint32_t n_batches, uint64_t max_reads, uint64_t
     c->max_reads = max_reads; c->max_con = max_con; c->want_rows = want_rows != 0;
     const size_t row_len = 2 * (size_t)c->maxhits + 2;
     c->batches.resize(n_batches);
-    mcint::NearDeviceMemory near(c->device);             // the pinned pages go to the GPU's NUMA node
-    const unsigned hflags = near.active ? hipHostMallocNumaUser : hipHostMallocDefault;
+    const unsigned hflags = hipHostMallocDefault;
     for (auto &b : c->batches) {
         hipError_t e = hipHostMalloc((void **)&b.h_ptr, (max_reads + 1) * 4, hflags);
         if (e == hipSuccess) e = hipHostMalloc((void **)&b.h_con, max_con * 2, hflags);

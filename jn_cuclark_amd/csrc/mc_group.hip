@@ -290,10 +290,8 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
     const size_t b_ptr = up((max_reads + 1) * 4), b_con = up(max_con * 2), b_fin = up(max_reads * MC_FINAL_ROW * 2),
                  b_rows = g->want_rows ? up(max_reads * row_len * 2) : 0;
     const size_t per_batch = b_ptr + b_con + b_fin + b_rows;
-    // portable: every device of the group copies from / into these; on the NUMA node of the first device
-    mcint::NearDeviceMemory near(g->ctx[0]->device);
-    hipError_t e = hipHostMalloc((void **)&g->h_slab, per_batch * n_batches,
-                                 hipHostMallocPortable | (near.active ? hipHostMallocNumaUser : 0u));
+    // portable: every device of the group copies from / into these
+    hipError_t e = hipHostMalloc((void **)&g->h_slab, per_batch * n_batches, hipHostMallocPortable);
     if (e != hipSuccess) return oom("pinned batch buffers", e);
     g->batches.resize(n_batches);
     for (uint32_t i = 0; i < n_batches; i++) {

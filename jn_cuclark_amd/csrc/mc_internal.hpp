@@ -120,16 +120,6 @@ namespace mcint {
 
 int set_dev(mc_ctx *c);
 
-// Pinned host buffers belong on the NUMA node the GPU hangs off: measured on the two-socket MI355X host,
-// H2D runs at 57 GB/s from the near node and at 28 GB/s from the far one (D2H 57 either way; tools/h2d_numa.py),
-// and the HIP allocator places the pages wherever the calling thread happens to run.  While an object of this
-// type lives, the calling thread's memory policy prefers the node of `device` (best effort: no node
-// information or no permission = no change).
-struct NearDeviceMemory {
-    explicit NearDeviceMemory(int device);
-    ~NearDeviceMemory();
-    bool active = false;
-};
 // one query launch on `st` (no synchronisation)
 int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads, uint64_t n_con,
                  uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st);

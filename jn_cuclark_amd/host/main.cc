@@ -467,6 +467,9 @@ struct Classifier {
 
 int main(int argc, char **argv)
 {
+    // more hardware queues than the runtime's default of 4, before it starts: the copy-in, compute and copy-out
+    // queues of the batch interface must not share one (csrc/mc_api.hip, mc_open)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (argc == 2) {
         const std::string v(argv[1]);
         if (v == "--help" || v == "--HELP") { print_usage(); return 0; }

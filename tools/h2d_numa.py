@@ -1,5 +1,8 @@
 """H2D / D2H rate of pinned buffers allocated while the process is bound to the CPUs of each NUMA node (first touch
-decides where the pages live): is the 30 GB/s of the pipelined path a placement problem?  Run on the GPU box."""
+decides where the pages live).  On the two-socket MI355X hosts one node copies to the card at 57 GB/s and the other at
+22-28 GB/s (D2H 57 either way) -- and not always the node sysfs names for the card.  Binding the library's pinned
+buffers (by sysfs, then by a measured probe) was tried and dropped: the streamed rate of bench.py moved between 530 and
+1020 Mreads/s from box to box with or without it.  Run on the GPU box."""
 import glob
 import os
 import time
@@ -44,26 +47,3 @@ for node in nodes:
     del h
 os.sched_setaffinity(0, allowed)
 
-# the library's own pinned batch buffers (mc_alloc_batches binds them to the GPU's node)
-import ctypes as C
-import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jn_cuclark_amd import _lib
-lib = _lib.load_library()
-hip = C.CDLL("libamdhip64.so")
-for bind in (nodes + [None]):
-    os.sched_setaffinity(0, [c for c in cpus_of(bind) if c in allowed] if bind is not None else allowed)
-    h = C.c_void_p()
-    _lib.check(lib.mc_open(C.byref(h), 0, 31, 1610612741, 16, 15))
-    _lib.check(lib.mc_alloc_batches(h, 1, 25_000_000, 500_000_000, 0))
-    p, c_, f, r = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-    _lib.check(lib.mc_batch_buffers(h, 0, C.byref(p), C.byref(c_), C.byref(f), C.byref(r)))
-    C.memset(c_.value, 1, 1_000_000_000)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        hip.hipMemcpy(C.c_void_p(d.data_ptr()), c_, C.c_size_t(1_000_000_000), C.c_int(1))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print("library buffers, thread on node %s: h2d %.1f GB/s" % (bind, 5 * 1e9 / dt / 1e9), flush=True)
-    lib.mc_close(h)
