@@ -11,9 +11,10 @@
  *   - every function returns MC_OK (0) or a negative MC_E* code; the message is
  *     available from mc_last_error() (thread-local).  Nothing calls exit(): the
  *     reference's CUERR macro (CuClarkDB.cu:45-53) printed and exited instead.
- *   - one mc_ctx = one GPU (one HIP device, its streams, one database shard).
- *     Multi-GPU = one process (or thread) per GPU, each with its own ctx, combined
- *     with mc_merge_rows_device / mc_result_rows_device after the exchange.
+ *   - one mc_ctx = one GPU (one HIP device, its streams, one database or one part of it).
+ *     Multi-GPU = mc_group.h (one process drives all GPUs, as the reference's object does),
+ *     or one process per GPU, each with its own ctx, combined with mc_merge_result_device
+ *     after the exchange (jn_cuclark_amd/dist.py).
  *   - HTSIZE and MAXHITS are run-time parameters (the reference compiles two
  *     binaries, src/parameters.hh:37-48 vs src/parameters_light_hh:38-49).
  *   - wire types are the reference's: containers/labels/results are uint16_t,
@@ -173,8 +174,9 @@ int mc_batch_buffers(mc_ctx *ctx, uint32_t batch, uint32_t **reads_ptr,
                      uint16_t **containers, uint16_t **final_rows, uint16_t **sparse_rows);
 
 /* Enqueue one filled batch: H2D, query kernel, D2H, completion event; returns
- * without waiting.  Batches alternate between two HIP streams so the copies of
- * one overlap the kernel of the other.
+ * without waiting.  Three queues chained by events (copy in, compute, copy out) and two
+ * device slots: the copy-in of the next batch and the copy-out of the previous one run
+ * under the kernel of the current one.  Batches may be submitted in any order.
  * replaces: readyBatch + queryBatch (CuClarkDB.cu:820-987). */
 int mc_submit(mc_ctx *ctx, uint32_t batch, uint64_t n_reads, uint64_t n_containers,
               uint32_t flags);
