@@ -266,7 +266,7 @@ def main():
             },
         }
 
-        # ---- host-to-host: the streaming interface of the boundary (pinned buffers, two streams) ----
+        # ---- host-to-host: the streaming interface of the boundary (pinned buffers, three queues) ----
         if world == 1 and not args.no_pipelined:
             out["pipelined"] = pipelined_rate(db, torch, np, rp_t, con_t, n_reads, fin)
 
@@ -379,8 +379,8 @@ def source_sha():
 def pipelined_rate(db, torch, np, rp_t, con_t, n_reads, fin_expected, nb=4, rounds=5):
     """PCIe-inclusive rate through mc_alloc_batches / mc_submit / mc_wait (reference malloc / queryBatch /
     waitForBatch, CuClarkDB.cu:321-421, :835-987): the step's batch cut into `nb` batches whose packed reads start
-    in pinned HOST memory and whose results end there; all nb in flight, alternating on two streams, so the copies
-    of one overlap the kernel of the other.  Never the headline value."""
+    in pinned HOST memory and whose results end there; all nb in flight, a batch resubmitted as soon as its previous
+    results were waited for; copy-in, kernel and copy-out run on three queues.  Never the headline value."""
     per = n_reads // nb
     rp_h = rp_t.cpu().numpy().view(np.uint32)
     con_h = con_t.cpu().numpy().view(np.uint16)

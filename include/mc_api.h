@@ -63,8 +63,8 @@ typedef struct mc_db_info {
     uint64_t shard_begin;     /* first bucket held by this ctx                      */
     uint64_t shard_end;       /* one past the last bucket held by this ctx          */
     uint64_t n_keys;          /* k-mers resident on this device                     */
-    uint64_t n_overflow_buckets; /* buckets larger than a line, kept in the side table */
-    uint64_t n_overflow_keys;
+    uint64_t n_overflow_buckets; /* bucket-line table: buckets larger than a line (kept in a side CSR); minimizer index: extra lines */
+    uint64_t n_overflow_keys;    /* bucket-line table: k-mers of those buckets; minimizer index: k-mers in the chains of crowded lines */
     uint32_t line_bytes;      /* bucket line size chosen at load (64 or 128)         */
     uint32_t line_capacity;   /* k-mers per line                                     */
     uint64_t device_bytes;    /* HBM held by the database                            */
@@ -111,7 +111,8 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize,
 int mc_close(mc_ctx *ctx);
 
 /* Load <base>.sz/.ky/.lb, keep the buckets [shard_begin, shard_end) (0,0 = all),
- * upload and re-lay them out as bucket lines in HBM.
+ * and lay them out in HBM as the minimizer index (default; streamed from the files in two passes) or the
+ * bucket-line table (mc_db_info.index_kind says which).
  * replaces: CuClarkDB::read + swapDbParts (CuClarkDB.cu:463-815).  key_bytes =
  * sizeof(HKMERr) of the files (2, 4 or 8).  sampling = the -s factor (<=1: none,
  * CuClarkDB.cu:490-513).  MC_EIO when a file is missing (the reference returns

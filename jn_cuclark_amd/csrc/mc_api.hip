@@ -213,7 +213,7 @@ int index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes
     return index_add_device(c, d_sz, d_raw, key_bytes, d_labels, n_keys, b0, b1);
 }
 
-// between the passes: sizes known -> headers, extra lines, side table
+// between the passes: sizes known -> headers, extra lines
 int index_next_pass(mc_ctx *c)
 {
     if (!c->build.open || c->build.pass != 0) return fail(MC_ESTATE, "mc_index_next_pass out of order");

@@ -1,5 +1,5 @@
 """GPU suite: the in-HBM minimizer index beyond the plain case -- line-range parts (what the GPUs of a
-multi-GPU job hold), the streamed two-pass build, crowded minimizers (extra lines, side table).
+multi-GPU job hold), the streamed two-pass build, crowded minimizers (extra lines, hashed chains).
 Everything is compared with the oracle on the unsharded table: bit-exact."""
 import os
 
