@@ -131,17 +131,35 @@ def main():
         genomes = genomes_h.to(dev)
         del genomes_h
     else:
+        # The table is generated in 16 bucket-range chunks and fed to the index build chunk by chunk, once per build
+        # pass (the generator is deterministic), exactly as a loader streams the files: neither the raw arrays of the
+        # whole table (39 GB) nor anything else sits in HBM next to the index while it is built, so the index takes the
+        # sparsest fill the card allows.  A first round of generation counts the k-mers (and keeps a host copy of the
+        # table for the oracle when one is wanted).
         genomes = synth_gpu.make_genomes(args.targets, args.genome_len, seed=31, device=dev)
-        d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, k, ht, args.targets, args.lam, genomes=genomes)
-        n_keys = int(d_keys.numel())
-        if shard_mode:      # line-range part of the whole table (the table itself is generated on every rank)
-            db.read_chunks(lambda: [(d_sz, d_keys, d_labels, 0, ht)], n_keys, part=rank, n_parts=world, device=True)
-        else:
-            db.read_device(d_sz, d_keys, d_labels)
-        nonempty = float((d_sz != 0).float().mean().item()) if rank == 0 else 0.0
-        if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.verify == 0):
-            raw_host = (d_sz.cpu().numpy(), d_keys.cpu().numpy(), d_labels.cpu().numpy())
-        del d_sz, d_keys, d_labels
+        want_host = rank == 0 and world == 1 and not (args.no_cpu_baseline and args.verify == 0)
+        n_ranges = 16
+        ranges = [(ht * j // n_ranges, ht * (j + 1) // n_ranges) for j in range(n_ranges)]
+        host_parts, n_keys, nonzero = [], 0, 0
+
+        def synth_chunks():
+            for b0, b1 in ranges:
+                d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, k, ht, args.targets, args.lam, genomes=genomes, shard=(b0, b1))
+                yield d_sz, d_keys, d_labels, b0, b1
+                del d_sz, d_keys, d_labels
+
+        for d_sz, d_keys, d_labels, b0, b1 in synth_chunks():
+            n_keys += int(d_keys.numel())
+            if rank == 0:
+                nonzero += int((d_sz != 0).sum().item())
+            if want_host:
+                host_parts.append((d_sz.cpu().numpy(), d_keys.cpu().numpy(), d_labels.cpu().numpy()))
+        nonempty = nonzero / ht
+        torch.cuda.empty_cache()
+        db.read_chunks(synth_chunks, n_keys, part=rank if shard_mode else 0, n_parts=world if shard_mode else 1, device=True)
+        if want_host:
+            raw_host = tuple(np.concatenate([p_[i] for p_ in host_parts]) for i in range(3))
+        del host_parts
     torch.cuda.empty_cache()
     info = db.db_info()
     torch.cuda.synchronize()
@@ -226,6 +244,7 @@ def main():
                 tj = json.load(open(tpath))
                 if (tj.get("reads_per_launch") == n_reads and tj.get("kernel") == kernel_name and tj.get("htsize") == ht
                         and tj.get("db", "synthetic") == args.db and tj.get("read_len", 150) == args.read_len
+                        and tj.get("kmers_per_line") == round(n_keys / max(1, info["n_lines"]), 2)
                         and tj.get("source_sha") == source_sha()):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:

@@ -25,6 +25,7 @@ out = {
         os.path.relpath(sys.argv[1], ROOT), line["roofline"]["kernel"]),
     "kernel": line["roofline"]["kernel"], "htsize": line["config"]["htsize"], "db": line["config"].get("db", "synthetic"),
     "reads_per_launch": line["config"]["reads_per_step"], "read_len": 150, "line_bytes": line_bytes,
+    "kmers_per_line": line["config"]["index"]["kmers_per_line"],
     "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "hbm_bytes_per_launch": int(hbm),
     "rdreq": vals.get("TCC_EA0_RDREQ_sum"),
     "source_sha": bench.source_sha(),
