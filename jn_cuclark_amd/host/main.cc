@@ -227,6 +227,32 @@ struct Classifier {
         std::string err;
         auto now = []() { struct timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + tv.tv_usec / 1e6; };
         const double ts0 = now();
+        // Pinning the batch buffers takes 6-10 ms and needs no CPU: for a large file it runs NEXT TO the indexer, with
+        // sizes guessed from the head of the file (10 % head room); the guess is checked against the index below
+        // and the buffers are allocated again if it was too small.
+        size_t guess_reads = 0, guess_con = 0, guess_nbuf = 0;
+        std::thread early_alloc;
+        int early_rc = MC_OK;
+        std::string early_err;
+        if (nb >= (8u << 20) && !opt.dump) {
+            ReadIndex H;
+            std::string herr;
+            const size_t head = 1u << 20;
+            if (index_reads(map, head, H, herr) && H.size() > 8) {
+                const size_t hn = H.size() - 1;                                  // the last record of the head is cut short
+                const double per_read = (double)H.spos[hn] / (double)hn;         // bytes per record
+                const double con_per_read = (double)container_bound(H, 0, hn, (unsigned)opt.k) / (double)hn;
+                const size_t nbatch_g = std::max<size_t>(1, opt.batches);
+                guess_reads = (size_t)((double)nb / per_read / (double)nbatch_g * 1.10) + 64;
+                guess_con = (size_t)((double)guess_reads * con_per_read * 1.05) + 64;
+                guess_nbuf = std::min(nbatch_g, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
+                if (guess_con <= 0xFFFFFFFFull)
+                    early_alloc = std::thread([&]() {
+                        early_rc = mc_group_alloc_batches(grp, (uint32_t)guess_nbuf, guess_reads, guess_con, opt.ext ? 1 : 0);
+                        if (early_rc != MC_OK) early_err = mc_last_error();
+                    });
+            }
+        }
         if (!index_reads_parallel(map, nb, (int)opt.cpu, R, err)) { std::cerr << err << std::endl; std::exit(-1); }
         const double ts1 = now();
         n_objects = R.size();
@@ -251,7 +277,14 @@ struct Classifier {
         // Pinning costs ~0.3 ms per MB, so the batches go through a ring of a few buffer sets instead: batch b
         // uses set b % nbuf and is packed once batch b - nbuf has been formatted.
         const size_t nbuf = opt.dump ? nbatch : std::min(nbatch, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
-        mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
+        bool have_buffers = false;
+        if (early_alloc.joinable()) {
+            early_alloc.join();
+            have_buffers = early_rc == MC_OK && guess_nbuf == nbuf && guess_reads >= max_reads && guess_con >= max_con;
+            if (!have_buffers && early_rc == MC_OK) mc_group_free_batches(grp);          // the guess was too small
+        }
+        if (!have_buffers)
+            mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
 
         const uint32_t flags = MC_F_FINAL | (opt.ext ? MC_F_ROWS : 0);
         std::vector<size_t> ncon(nbatch, 0);
