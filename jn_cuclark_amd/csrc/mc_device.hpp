@@ -136,7 +136,11 @@ struct QueryArgs {
 
 static constexpr int WAVES_PER_BLOCK = 4;
 static constexpr int BLOCK_THREADS   = 64 * WAVES_PER_BLOCK;
-static constexpr int GROUP_READS     = 16;     // reads staged per wave at a time
+#ifndef MC_GROUP_READS
+#define MC_GROUP_READS 16
+#endif
+static constexpr int GROUP_READS     = MC_GROUP_READS;     // reads staged per wave at a time (at most 32: one lane per read offset)
+static_assert(GROUP_READS >= 1 && GROUP_READS <= 32, "group size");
 #ifndef MC_STAGE_CON
 #define MC_STAGE_CON 1024
 #endif

@@ -118,6 +118,29 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v)
     return v;
 }
 
+// Lane masks straight from one compare.  A ballot of a condition that is also used per lane (or of
+// anything but a single compare) is compiled to a select of 0/1 and a second compare; these are one
+// v_cmp into a scalar pair, combined with scalar ANDs, and turned back into a per-lane condition for
+// free with __builtin_amdgcn_inverse_ballot_w64.  (Lanes that are switched off read as 0.)
+__device__ __forceinline__ uint64_t mask_ne(uint32_t a, uint32_t b)
+{
+    uint64_t m;
+    asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint64_t mask_lt_s(uint32_t a, uint32_t uniform_b)       // a < b, b wave-uniform
+{
+    uint64_t m;
+    asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_b), "v"(a));
+    return m;
+}
+__device__ __forceinline__ uint64_t mask_eq_s(uint32_t a, uint32_t uniform_b)
+{
+    uint64_t m;
+    asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_b), "v"(a));
+    return m;
+}
+
 __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, uint32_t uniform_lane)
 {
     return (uint64_t)lane_bcast((uint32_t)v, uniform_lane) | ((uint64_t)lane_bcast((uint32_t)(v >> 32), uniform_lane) << 32);
@@ -515,13 +538,19 @@ void mz_query_kernel(const MzArgs A)
     constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - (MZ_MAXW - 1) (mmer_len)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
-    const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
-    const uint64_t gstride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    // a batch holds fewer than 2^32 reads and containers (reads_ptr is u32; launch_query checks): 32-bit
+    // counters, half the scalar registers
+    const uint32_t n_reads = (uint32_t)a.n_reads, n_con = (uint32_t)a.n_containers;
+    const uint32_t n_groups = (n_reads + (GROUP_READS - 1)) / GROUP_READS;
+    const uint32_t gstride = gridDim.x * WAVES_PER_BLOCK;
+    // wave-uniform switches are tested where they are used, from ONE scalar register (hoisted out of the
+    // loops they become lane masks that live in -- and are spilled from -- two registers each)
+    auto flags_now = [&]() -> uint32_t { uint32_t f = a.flags; asm volatile("" : "+s"(f)); return f; };
     const uint32_t row_len = 2u * a.maxhits + 2u;
 
-    for (uint64_t g = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; g < n_groups; g += gstride) {
-        const uint64_t r0 = g * GROUP_READS;
-        const uint32_t nr = (uint32_t)((a.n_reads - r0) < GROUP_READS ? (a.n_reads - r0) : GROUP_READS);
+    for (uint32_t g = blockIdx.x * WAVES_PER_BLOCK + wave; g < n_groups; g += gstride) {
+        const uint32_t r0 = g * GROUP_READS;
+        const uint32_t nr = (n_reads - r0) < (uint32_t)GROUP_READS ? (n_reads - r0) : (uint32_t)GROUP_READS;
         uint32_t ptr_v = 0;
         {
             const uint32_t lg = opaque(lane);
@@ -543,14 +572,14 @@ void mz_query_kernel(const MzArgs A)
                 // the slice holds the containers as big-endian 64-bit words (4 containers each,
                 // first base in the top bits): container i lives at u16 index i ^ 3, and any
                 // k-mer is cut from two consecutive aligned words
-                if (gi + 8u <= a.n_containers) {
+                if (gi + 8u <= (uint64_t)n_con) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(a.containers + gi);
                     *reinterpret_cast<uint4 *>(slice + j) =
                         make_uint4(__builtin_rotateright32(v.y, 16), __builtin_rotateright32(v.x, 16),
                                    __builtin_rotateright32(v.w, 16), __builtin_rotateright32(v.z, 16));
                 } else {
                     for (uint32_t t = 0; t < 8u; t++)
-                        slice[(j + t) ^ 3u] = (gi + t < a.n_containers) ? a.containers[gi + t] : (uint16_t)0;
+                        slice[(j + t) ^ 3u] = (gi + t < (uint64_t)n_con) ? a.containers[gi + t] : (uint16_t)0;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -563,7 +592,7 @@ void mz_query_kernel(const MzArgs A)
                 const uint32_t li = i - c0a;
                 return slice[(li < (uint32_t)(MZ_STAGE_CON + 12) ? li : (uint32_t)(MZ_STAGE_CON + 12)) ^ 3u];
             } else {
-                const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
+                const uint32_t ii = i < n_con ? i : n_con - 1u;
                 return a.containers[ii];
             }
         };
@@ -591,7 +620,7 @@ void mz_query_kernel(const MzArgs A)
         for (uint32_t ri = rs; ri < re; ri++) {
             const uint32_t beg = lane_bcast(ptr_v, ri);
             uint32_t end = lane_bcast(ptr_v, ri + 1u);
-            if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
+            if (end > n_con) end = n_con;
             uint32_t acc_t = 0xFFFFFFFFu, acc_c = 0, n_acc = 0;
 
             uint32_t pp = beg;
@@ -612,14 +641,23 @@ void mz_query_kernel(const MzArgs A)
                     uint64_t c[MZ_NS];
                     uint32_t line[MZ_NS], run[MZ_NS];
                     const bool last_step = base + 64u * MZ_NS >= nk;                // wave-uniform
+                    // The m-mers of the part sit at positions 0 .. nm-1; the W-1 behind its last k-mer start
+                    // no k-mer.  When they all fall inside this step's 64*NS positions (every read of up to
+                    // 64*NS - W + k bases: 148 at k = 31 with 11 windows, 150 with 9) the lanes that own those
+                    // positions cut them in the same instructions as everybody else -- the first m bases of
+                    // the 32 bases they read are inside the part -- and the tail code below is skipped.
+                    const uint32_t nm = nk + (W - 1u);
+                    const bool tail_in_step = nm - base <= 64u * MZ_NS;             // wave-uniform
                     const uint32_t p0 = base + 2u * lane;
-                    active[0] = p0 < nk;
-                    active[1] = p0 + 1u < nk;
-                    const bool inpart[MZ_NS] = {active[0], active[1]};
+                    const uint64_t in0 = mask_lt_s(p0, nk), in1 = mask_lt_s(p0, nk - 1u);     // positions p0, p0 + 1 hold a k-mer
+                    active[0] = __builtin_amdgcn_inverse_ballot_w64(in0);
+                    active[1] = __builtin_amdgcn_inverse_ballot_w64(in1);
                     uint64_t x0 = 0, x1 = 0, rc0 = 0, rc1 = 0;
                     uint64_t key0 = MZ_KEY_NONE, key1 = MZ_KEY_NONE;
                     c[0] = 0; c[1] = 0;
-                    if (active[0]) {
+                    // Staged: no predicate at all.  The LDS reads are clamped, and what a lane past the last
+                    // m-mer computes is read by no k-mer of the part (a window ends at position nm - 1).
+                    if (STAGED || p0 < (tail_in_step ? nm : nk)) {
                         if constexpr (STAGED) {
                             uint32_t j0 = first - c0a + (p0 >> 3);                    // container index in the slice
                             if (j0 > (uint32_t)(MZ_STAGE_CON + 4)) j0 = (uint32_t)(MZ_STAGE_CON + 4);
@@ -639,7 +677,7 @@ void mz_query_kernel(const MzArgs A)
                         key0 = mmer_key2(x0 >> (2u * (k - m)), rc0 & mmask);        // first m bases, both strands
                         c[0] = x0 < rc0 ? x0 : rc0;
                         // also right for the lane whose second position is nk (no k-mer there): the m-mer at nk
-                        // lies inside the part, and the tail writer below stores the same key again
+                        // lies inside the part
                         key1 = mmer_key2(x1 >> (2u * (k - m)), rc1 & mmask);
                         c[1] = x1 < rc1 ? x1 : rc1;
                         if constexpr (SHARDED) {
@@ -662,22 +700,24 @@ void mz_query_kernel(const MzArgs A)
                         typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
                         *reinterpret_cast<u64x2 *>(keyv + 2u * lane) = u64x2{key0, key1};
                     }
-                    // the W-1 m-mers that start behind the part's last k-mer (positions nk .. nk+W-2) all
-                    // lie inside that k-mer: cut from its value, stored on top of the stores above
-                    const uint32_t q = nk - 1u - base;                               // last k-mer: lane q/2, half q%2
-                    uint64_t x_last = 0, rc_last = 0;
-                    if (last_step) {                                                 // every lane takes part in the select
-                        x_last = lane_bcast64((q & 1u) ? x1 : x0, q >> 1);
-                        rc_last = lane_bcast64((q & 1u) ? rc1 : rc0, q >> 1);
-                    }
-                    if (lane < W - 1u) {
-                        const uint32_t ln = opaque(lane);
-                        if (last_step) {
-                            const uint32_t i = ln + 1u;
-                            keyv[64 * MZ_NS + ln] = MZ_KEY_NONE;
-                            keyv[q + i] = mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
-                        } else {
-                            keyv[64 * MZ_NS + ln] = mmer_key(bases_at(first, base + 64u * MZ_NS + ln, m, mmask), m);
+                    if (!tail_in_step) {
+                        // the W-1 m-mers that start behind the part's last k-mer (positions nk .. nk+W-2) all
+                        // lie inside that k-mer: cut from its value, stored on top of the stores above
+                        const uint32_t q = nk - 1u - base;                               // last k-mer: lane q/2, half q%2
+                        uint64_t x_last = 0, rc_last = 0;
+                        if (last_step) {                                                 // every lane takes part in the select
+                            x_last = lane_bcast64((q & 1u) ? x1 : x0, q >> 1);
+                            rc_last = lane_bcast64((q & 1u) ? rc1 : rc0, q >> 1);
+                        }
+                        if (lane < W - 1u) {
+                            const uint32_t ln = opaque(lane);
+                            if (last_step) {
+                                const uint32_t i = ln + 1u;
+                                keyv[64 * MZ_NS + ln] = MZ_KEY_NONE;
+                                keyv[q + i] = mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
+                            } else {
+                                keyv[64 * MZ_NS + ln] = mmer_key(bases_at(first, base + 64u * MZ_NS + ln, m, mmask), m);
+                            }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -692,23 +732,26 @@ void mz_query_kernel(const MzArgs A)
 #pragma unroll
                         for (int i = 2; i < MZ_MAXW; i++) mid = key_min(mid, v[i]);
                         const uint64_t K0 = key_min(v[0], mid), K1 = key_min(mid, v[MZ_MAXW]);
-                        line[0] = inpart[0] ? line_of(K0, A.n_lines) : 0xFFFFFFFFu;
-                        line[1] = inpart[1] ? line_of(K1, A.n_lines) : 0xFFFFFFFFu;
+                        // (what a lane without a k-mer computes here is never looked at: a position with a
+                        // k-mer has one before it, and only leaders and active lanes use their line)
+                        line[0] = line_of(K0, A.n_lines);
+                        line[1] = line_of(K1, A.n_lines);
+                        uint64_t own0 = in0, own1 = in1;
                         if constexpr (SHARD == MZ_LINES) {
                             // local line index; k-mers of lines this context does not own drop out here,
                             // and only owned runs are numbered (fetched, matched, scored)
-#pragma unroll
-                            for (int s = 0; s < MZ_NS; s++) {
-                                line[s] -= A.line0;
-                                active[s] = inpart[s] && line[s] < A.n_local;
-                            }
+                            line[0] -= A.line0;
+                            line[1] -= A.line0;
+                            own0 &= mask_lt_s(line[0], A.n_local);
+                            own1 &= mask_lt_s(line[1], A.n_local);
+                            active[0] = __builtin_amdgcn_inverse_ballot_w64(own0);
+                            active[1] = __builtin_amdgcn_inverse_ballot_w64(own1);
                         }
                         // second line of the lane before (DPP wave_shr:1); nothing before lane 0
                         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)line[1], 0x138, 0xf, 0xf, false);
-                        leader[0] = inpart[0] && line[0] != prev;
-                        leader[1] = inpart[1] && line[1] != line[0];
-                        if constexpr (SHARD == MZ_LINES) { leader[0] = leader[0] && active[0]; leader[1] = leader[1] && active[1]; }
-                        const uint64_t b0 = __ballot(leader[0]), b1 = __ballot(leader[1]);
+                        const uint64_t b0 = mask_ne(line[0], prev) & own0, b1 = mask_ne(line[1], line[0]) & own1;
+                        leader[0] = __builtin_amdgcn_inverse_ballot_w64(b0);
+                        leader[1] = __builtin_amdgcn_inverse_ballot_w64(b1);
                         // leaders in lower lanes (v_mbcnt) = index of this lane's first run
                         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u))
                                              + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
@@ -745,13 +788,14 @@ void mz_query_kernel(const MzArgs A)
                         // past the last run re-read that run's line (same request, no predication).
                         u32x4 v[MZ_RUNS / 8];
                         const uint32_t lf = opaque(lane);
+                        const uint8_t *lane_base = A.lines + (lf & 7u) * 16u;      // this lane's 16 bytes of a line
+                        const uint32_t last = nb - 1u;
 #pragma unroll
                         for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
                             if (8u * rd < nb) {
                                 const uint32_t j = 8u * rd + (lf >> 3);
-                                const uint32_t jc = j < nb ? j : nb - 1u;
-                                const uint32_t rl = runline[jc];
-                                const u32x4 *src = reinterpret_cast<const u32x4 *>(A.lines + (uint64_t)rl * MZ_LINE) + (lf & 7u);
+                                const uint32_t rl = runline[j < last ? j : last];
+                                const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_base + ((uint64_t)rl << 7));
                                 if constexpr (SHARDED) {
                                     v[rd] = u32x4{0u, 0u, 0u, 0u};
                                     if (rl != 0xFFFFFFFFu) v[rd] = __builtin_nontemporal_load(src);
@@ -776,8 +820,9 @@ void mz_query_kernel(const MzArgs A)
                                 uint32_t hdr, eb;
                                 hit[s] = mz_match_line(L, c[s], lab[s], hdr, eb);
                                 // rare: lines beyond the first (Bloom bits are set only where extra lines exist)
-                                const uint32_t xm = extra_mask(c[s]);
-                                if (!hit[s] && (hdr & xm) == xm) {
+                                // (a line without extra lines has an empty Bloom word: the k-mer's own bits are
+                                // computed only behind that test)
+                                if (!hit[s] && hdr >= 0x10000u && (hdr & extra_mask(c[s])) == extra_mask(c[s])) {
                                     // this k-mer's chain of the line: the one of its 2^s chains the k-mer hashes to
                                     // (s = 0: the only one), and the one behind it when bit 2 says that some chain
                                     // was full
@@ -828,11 +873,10 @@ void mz_query_kernel(const MzArgs A)
                         many = 0;
 #pragma unroll
                         for (int s = 0; s < MZ_NS; s++) {
-                            const uint64_t same = __ballot(hit[s] && lab[s] == t);
+                            const uint64_t same = mask_eq_s(lab[s], t) & mm[s];      // mm: hits not counted yet
                             cnt += (uint32_t)__popcll(same);
                             mm[s] &= ~same;
                             many |= mm[s];
-                            if (lab[s] == t) hit[s] = false;
                         }
                         const uint64_t ex = __ballot(acc_t == t);
                         if (ex) {
@@ -852,10 +896,10 @@ void mz_query_kernel(const MzArgs A)
             }
 
             // ---- finalisation (identical to query_kernel) ---------------------
-            const uint64_t rd = r0 + ri;
+            const uint64_t rd = (uint64_t)(r0 + ri);
             bool valid = lane < n_acc;
             uint32_t rank = 0;
-            const bool need_rank = (a.flags & 2u) || (n_acc > a.maxhits);
+            const bool need_rank = (flags_now() & 2u) || (n_acc > a.maxhits);
             if (need_rank) {
                 for (uint32_t j = 0; j < n_acc; j++) {
                     const uint32_t tj = lane_bcast(acc_t, j);
@@ -863,17 +907,17 @@ void mz_query_kernel(const MzArgs A)
                 }
                 if (n_acc > a.maxhits) {
                     valid = valid && rank < a.maxhits;
-                    if (lane == 0) atomicAdd(a.over_maxhits, 1ull);
+                    if (__builtin_amdgcn_inverse_ballot_w64(1ull)) atomicAdd(a.over_maxhits, 1ull);      // lane 0
                 }
             }
             const uint32_t n_keep = n_acc > a.maxhits ? a.maxhits : n_acc;
-            if (a.flags & 2u) {
+            if (flags_now() & 2u) {
                 uint16_t *row = a.sparse_rows + rd * row_len;
-                if (lane == 0) row[0] = (uint16_t)n_keep;
+                if (__builtin_amdgcn_inverse_ballot_w64(1ull)) row[0] = (uint16_t)n_keep;           // lane 0
                 if (valid) { row[1 + 2 * rank] = (uint16_t)acc_t; row[2 + 2 * rank] = (uint16_t)sat_u16(acc_c); }
                 for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
             }
-            if (a.flags & 1u) {
+            if (flags_now() & 1u) {
                 // the row [sumN, idxBest+1, best, idxSecond+1, second] as five wave-uniform values
                 uint32_t o0, o1, o2, o3 = 0u, o4 = 0u;
                 if (n_acc <= 1u) {              // most reads hit no target or one: lane 0 has it all

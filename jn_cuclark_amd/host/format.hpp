@@ -23,12 +23,13 @@ inline int fmt_ratio_g(char *dst, uint64_t a, uint64_t b)
     if (a == 0) { dst[0] = '0'; return 1; }
     if (a == b) { dst[0] = '1'; return 1; }
     // decimal exponent X of a/b: the smallest p >= 1 with a * 10^p >= b gives X = -p
+    // (64 bits are enough: a * 10^p < 10 b <= 10 * 2^20, times 10^5 stays below 2^44)
     int p = 1;
-    unsigned __int128 n = (unsigned __int128)a * 10u;
+    uint64_t n = a * 10u;
     while (n < b) { n *= 10u; p++; }
     n *= 100000u;                                   // a * 10^(p+5): six significant digits before the point
-    uint64_t q = (uint64_t)(n / b);
-    const uint64_t r = (uint64_t)(n % b);
+    uint64_t q = n / b;
+    const uint64_t r = n - q * b;
     if (2 * r == b) return 0;                       // exact tie: printf rounds the double, not the ratio
     if (2 * r > b) q++;
     int X = -p;

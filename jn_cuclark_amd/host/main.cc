@@ -31,7 +31,9 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <array>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -214,35 +216,67 @@ struct Classifier {
         run_image(joined.data(), joined.size(), result);
     }
 
+    // One batch of the file on its way through the pipeline.  Its reads are either a slice of ONE index of the
+    // whole file (small files, --dump-batches, or after the streamed attempt gave up) or its own index of a
+    // byte range of the file (streamed: offsets relative to `text`).
+    struct Batch {
+        const ReadIndex *R = nullptr;
+        ReadIndex own;
+        const uint8_t *text = nullptr;
+        size_t r0 = 0, n = 0;           // reads [r0, r0 + n) of *R
+        size_t ncon = 0;
+        bool indexed = false, submitted = false;
+    };
+
     void run_image(const uint8_t *map, size_t nb, const char *result)
+    {
+        struct timeval t0, t1;
+        gettimeofday(&t0, nullptr);
+        // Large files are STREAMED: cut into byte ranges at record starts, one per batch, and each range is
+        // indexed, packed and submitted by one task -- no index of the whole file first, nothing waits for the
+        // last indexer thread, the GPU starts after 1/nbatch of the scanning.  The pinned buffers are sized
+        // from the head of the file; if a range turns out to hold more than they take, the attempt is given up
+        // and the file goes through the plan that indexes it as a whole (as small files and --dump-batches do).
+        size_t stream_min = 8u << 20;
+        if (const char *e = getenv("MC_STREAM_MIN_BYTES")) stream_min = (size_t)std::strtoull(e, nullptr, 10);
+        bool done = false;
+        if (nb >= stream_min && !opt.dump && (map[0] == '>' || map[0] == '@')) done = classify_image(map, nb, result, true);
+        if (!done) classify_image(map, nb, result, false);
+        gettimeofday(&t1, nullptr);
+        const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "Done in %.1fs (%zu reads/min, %zu reads)\n", diff,
+                      (size_t)(((double)n_objects) / diff * 60.0), n_objects);
+        std::cerr << buf << "Results: " << result << ".csv\n";
+    }
+
+    // false: the streamed attempt met a byte range its buffers do not take (nothing of the result is kept)
+    bool classify_image(const uint8_t *map, size_t nb, const char *result, const bool streamed)
     {
         const std::string csv = std::string(result) + ".csv";
         FILE *fout = std::fopen(csv.c_str(), "w");
-        if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return; }
-
-        struct timeval t0, t1;
-        gettimeofday(&t0, nullptr);
+        if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return true; }
 
         ReadIndex R;
         std::string err;
         auto now = []() { struct timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + tv.tv_usec / 1e6; };
         const double ts0 = now();
-        // Pinning the batch buffers takes 6-10 ms and needs no CPU: for a large file it runs NEXT TO the indexer, with
-        // sizes guessed from the head of the file (10 % head room); the guess is checked against the index below
-        // and the buffers are allocated again if it was too small.
+        // Pinning the batch buffers takes 6-10 ms and needs no CPU: for a large file it runs NEXT TO the indexing, with
+        // sizes guessed from the head of the file (10 % head room); the guess is checked against what the index
+        // says (whole-file plan: the buffers are allocated again if it was too small; streamed: see above).
         size_t guess_reads = 0, guess_con = 0, guess_nbuf = 0;
         std::thread early_alloc;
         int early_rc = MC_OK;
         std::string early_err;
-        if (nb >= (8u << 20) && !opt.dump) {
+        const size_t nbatch_g = std::max<size_t>(1, opt.batches);
+        if (nb >= (8u << 20) || streamed) {
             ReadIndex H;
             std::string herr;
-            const size_t head = 1u << 20;
-            if (index_reads(map, head, H, herr) && H.size() > 8) {
+            const size_t head = std::min<size_t>(nb, 1u << 20);
+            if (!opt.dump && index_reads(map, head, H, herr) && H.size() > 8) {
                 const size_t hn = H.size() - 1;                                  // the last record of the head is cut short
                 const double per_read = (double)H.spos[hn] / (double)hn;         // bytes per record
                 const double con_per_read = (double)container_bound(H, 0, hn, (unsigned)opt.k) / (double)hn;
-                const size_t nbatch_g = std::max<size_t>(1, opt.batches);
                 guess_reads = (size_t)((double)nb / per_read / (double)nbatch_g * 1.10) + 64;
                 guess_con = (size_t)((double)guess_reads * con_per_read * 1.05) + 64;
                 guess_nbuf = std::min(nbatch_g, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
@@ -252,69 +286,117 @@ struct Classifier {
                         if (early_rc != MC_OK) early_err = mc_last_error();
                     });
             }
+            if (streamed && !early_alloc.joinable()) { std::fclose(fout); return false; }     // no guess: whole-file plan
         }
-        if (!index_reads_parallel(map, nb, (int)opt.cpu, R, err)) { std::cerr << err << std::endl; std::exit(-1); }
-        const double ts1 = now();
-        n_objects = R.size();
-        const size_t nbatch = std::max<size_t>(1, std::min(opt.batches, n_objects));
-        std::vector<size_t> first(nbatch + 1);
-        for (size_t b = 0; b <= nbatch; b++) first[b] = n_objects * b / nbatch;
-        size_t max_reads = 1, max_con = 8;
-        {
-            std::vector<size_t> bound(nbatch, 0);
+
+        size_t nbatch, nbuf, cap_reads = 0, cap_con = 0;
+        std::vector<Batch> B;
+        std::vector<size_t> cut;                      // streamed: byte range of batch b = [cut[b], cut[b + 1])
+        double ts1, ts2;
+        if (streamed) {
+            nbatch = nbatch_g;
+            nbuf = guess_nbuf;
+            cap_reads = guess_reads; cap_con = guess_con;
+            const bool fastq = map[0] == '@';
+            cut.resize(nbatch + 1);
+            for (size_t b = 0; b <= nbatch; b++)
+                cut[b] = b == nbatch ? nb : record_start_at_or_after(map, nb, (size_t)((unsigned __int128)nb * b / nbatch), fastq);
+            B.resize(nbatch);
+            ts1 = ts2 = now();
+        } else {
+            if (!index_reads_parallel(map, nb, (int)opt.cpu, R, err)) { std::cerr << err << std::endl; std::exit(-1); }
+            ts1 = now();
+            const size_t n_all = R.size();
+            nbatch = std::max<size_t>(1, std::min(opt.batches, n_all));
+            B.resize(nbatch);
+            size_t max_reads = 1, max_con = 8;
+            {
+                std::vector<size_t> bound(nbatch, 0);
+                for (size_t b = 0; b < nbatch; b++) {
+                    B[b].R = &R; B[b].text = map; B[b].r0 = n_all * b / nbatch; B[b].n = n_all * (b + 1) / nbatch - B[b].r0;
+                    B[b].indexed = true;
+                }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
-            for (long b = 0; b < (long)nbatch; b++) bound[b] = container_bound(R, first[b], first[b + 1], (unsigned)opt.k);
-            for (size_t b = 0; b < nbatch; b++) {
-                max_reads = std::max(max_reads, first[b + 1] - first[b]);
-                max_con = std::max(max_con, bound[b]);
+                for (long b = 0; b < (long)nbatch; b++) bound[b] = container_bound(R, B[b].r0, B[b].r0 + B[b].n, (unsigned)opt.k);
+                for (size_t b = 0; b < nbatch; b++) {
+                    max_reads = std::max(max_reads, B[b].n);
+                    max_con = std::max(max_con, bound[b]);
+                }
             }
-        }
-        if (max_con > 0xFFFFFFFFull) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).", -1);
+            if (max_con > 0xFFFFFFFFull) die("ERROR: Batch overflow. Please increase the number of batches (-b <numberofbatches>).", -1);
 
-        // The reference pins buffers for ALL batches of a file at once (CuClarkDB::malloc, CuClarkDB.cu:321-421).
-        // Pinning costs ~0.3 ms per MB, so the batches go through a ring of a few buffer sets instead: batch b
-        // uses set b % nbuf and is packed once batch b - nbuf has been formatted.
-        const size_t nbuf = opt.dump ? nbatch : std::min(nbatch, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
-        bool have_buffers = false;
-        if (early_alloc.joinable()) {
-            early_alloc.join();
-            have_buffers = early_rc == MC_OK && guess_nbuf == nbuf && guess_reads >= max_reads && guess_con >= max_con;
-            if (!have_buffers && early_rc == MC_OK) mc_group_free_batches(grp);          // the guess was too small
+            // The reference pins buffers for ALL batches of a file at once (CuClarkDB::malloc, CuClarkDB.cu:321-421).
+            // Pinning costs ~0.3 ms per MB, so the batches go through a ring of a few buffer sets instead: batch b
+            // uses set b % nbuf and is packed once batch b - nbuf has been formatted.
+            nbuf = opt.dump ? nbatch : std::min(nbatch, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
+            bool have_buffers = false;
+            if (early_alloc.joinable()) {
+                early_alloc.join();
+                have_buffers = early_rc == MC_OK && guess_nbuf == nbuf && guess_reads >= max_reads && guess_con >= max_con;
+                if (!have_buffers && early_rc == MC_OK) mc_group_free_batches(grp);          // the guess was too small
+            }
+            if (!have_buffers)
+                mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
+            ts2 = now();
         }
-        if (!have_buffers)
-            mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
 
         const uint32_t flags = MC_F_FINAL | (opt.ext ? MC_F_ROWS : 0);
-        std::vector<size_t> ncon(nbatch, 0);
-        const double ts2 = now();
 
-        // One pool of worker threads runs two kinds of tasks: PACK (2-bit pack a batch into its pinned buffers,
-        // then submit it: H2D, kernel, D2H are asynchronous) and FORMAT (one slice of a finished batch's CSV
-        // lines).  The main thread waits for the batches in order, hands their slices to the pool and writes
-        // them out -- so packing, the GPU, formatting and writing overlap instead of running as three phases
-        // (the reference serialises queryBatch behind an omp critical and prints on one thread,
-        // src/CuCLARK_hh.hh:1737-1741, :2073-2121).
+        // One pool of worker threads runs three kinds of tasks: INDEX (streamed plan: the records of a byte range),
+        // PACK (2-bit pack a batch into its pinned buffers, then submit it: H2D, kernel, D2H are asynchronous) and
+        // FORMAT (one slice of a finished batch's CSV lines).  The main thread waits for the batches in order,
+        // hands their slices to the pool and writes them out -- so indexing, packing, the GPU, formatting and
+        // writing overlap instead of running as phases (the reference serialises queryBatch behind an omp critical
+        // and prints on one thread, src/CuCLARK_hh.hh:1737-1741, :2073-2121).
         Pool pool((int)std::max<size_t>(1, opt.cpu));
         std::mutex submit_mu, done_mu;
         std::condition_variable done_cv;
-        std::vector<char> submitted(nbatch, 0);
-        auto enqueue_pack = [&](size_t b) {
-            pool.run([&, b]() {
+        bool buffers_ready = !streamed, gave_up = false;        // under done_mu
+        auto index_batch = [&](size_t b) {
+            Batch &X = B[b];
+            std::string ierr;
+            const size_t len = cut[b + 1] - cut[b];
+            X.R = &X.own; X.text = map + cut[b]; X.r0 = 0;
+            if (len && !index_reads(map + cut[b], len, X.own, ierr)) { std::cerr << ierr << std::endl; std::exit(-1); }
+            X.n = X.own.size();
+            const bool fits = X.n <= cap_reads && container_bound(X.own, 0, X.n, (unsigned)opt.k) <= cap_con;
+            { std::lock_guard<std::mutex> lk(done_mu); X.indexed = true; if (!fits) gave_up = true; }
+            done_cv.notify_all();
+        };
+        auto pack_batch = [&](size_t b) {
+            Batch &X = B[b];
+            bool stop;
+            {
+                std::unique_lock<std::mutex> lk(done_mu);
+                done_cv.wait(lk, [&]() { return gave_up || (X.indexed && buffers_ready); });
+                stop = gave_up;
+            }
+            if (!stop) {
                 const uint32_t buf = (uint32_t)(b % nbuf);
                 uint32_t *ptr; uint16_t *con;
                 mc_check(mc_group_batch_buffers(grp, buf, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
-                ncon[b] = pack_reads(map, R, first[b], first[b + 1], (unsigned)opt.k, ptr, con);
-                {
-                    std::lock_guard<std::mutex> lk(submit_mu);
-                    mc_check(mc_group_submit(grp, buf, first[b + 1] - first[b], ncon[b], flags), "mc_group_submit");
-                }
-                { std::lock_guard<std::mutex> lk(done_mu); submitted[b] = 1; }
-                done_cv.notify_all();
-            });
+                X.ncon = pack_reads(X.text, *X.R, X.r0, X.r0 + X.n, (unsigned)opt.k, ptr, con);
+                std::lock_guard<std::mutex> lk(submit_mu);
+                mc_check(mc_group_submit(grp, buf, X.n, X.ncon, flags), "mc_group_submit");
+            }
+            { std::lock_guard<std::mutex> lk(done_mu); X.submitted = true; }
+            done_cv.notify_all();
         };
-        for (size_t b = 0; b < nbuf; b++) enqueue_pack(b);
+        auto enqueue_pack = [&](size_t b) { pool.run([&, b]() { pack_batch(b); }); };
+        if (streamed) {
+            // the first nbuf batches are indexed and packed by one task each; the ranges behind them are indexed
+            // by whoever is free (their buffers are in use until an earlier batch has been formatted)
+            for (size_t b = 0; b < nbuf; b++) pool.run([&, b]() { index_batch(b); pack_batch(b); });
+            for (size_t b = nbuf; b < nbatch; b++) pool.run([&, b]() { index_batch(b); });
+            early_alloc.join();
+            if (early_rc != MC_OK) die(std::string("mc_group_alloc_batches: ") + early_err);
+            { std::lock_guard<std::mutex> lk(done_mu); buffers_ready = true; }
+            done_cv.notify_all();
+        } else {
+            for (size_t b = 0; b < nbuf; b++) enqueue_pack(b);
+        }
 
         // header (reference :1951-1967)
         std::string head = "Object_ID";
@@ -331,77 +413,118 @@ struct Classifier {
         // a batch's lines are formatted in parallel slices (same printf conversions as the
         // reference, :2115-2118) and written in read order
         const int nfmt = (int)std::max<size_t>(1, opt.cpu);
+        // a slice's text: a plain buffer sized for the worst case up front and filled with pointer bumps
+        // (std::string appends and a 128-bit division per ratio were 3/4 of the formatting time)
+        struct Text {
+            char *p = nullptr;
+            size_t n = 0;
+            Text() = default;
+            Text(const Text &) = delete;
+            Text &operator=(const Text &) = delete;
+            ~Text() { std::free(p); }
+            void take(size_t cap) { std::free(p); p = static_cast<char *>(std::malloc(cap ? cap : 1)); n = 0; if (!p) die("out of memory", -1); }
+            void drop() { std::free(p); p = nullptr; n = 0; }
+        };
         struct Formatted {
-            std::vector<std::string> slice;
+            std::unique_ptr<Text[]> slice;
             std::vector<long> s_min, s_max, s_sum;
             int left = 0;
         };
+        size_t assign_max = 2;          // "NA"
+        for (const auto &nm : T.names) assign_max = std::max(assign_max, nm.size());
         std::vector<Formatted> fmt(nbatch);
         auto format_slice = [&](size_t b, int sl, const uint16_t *fin, const uint16_t *rows) {
             Formatted &F = fmt[b];
-            const size_t r0 = first[b], nr = first[b + 1] - first[b];
-            std::string &out = F.slice[sl];
-            out.clear();
-            out.reserve((nr / nfmt + 1) * 48);
+            const Batch &X = B[b];
+            const ReadIndex &RI = *X.R;
+            const uint8_t *text = X.text;
+            const size_t r0 = X.r0, nr = X.n;
+            const size_t i0 = r0 + nr * sl / nfmt, i1 = r0 + nr * (sl + 1) / nfmt;
+            // worst case: name + ",<gamma>," + assignment + ",<best>,<confidence>\n" (+ ",65535" per target when extended)
+            size_t cap = 0;
+            for (size_t i = i0; i < i1; i++) cap += std::min<size_t>(RI.name_e[i] - RI.name_s[i], OBJECTNAMEMAX - 1);
+            cap += (i1 - i0) * (2 * 64 + 16 + assign_max + (opt.ext ? 6 * (T.names.size() - 1) : 0));
+            Text &out = F.slice[sl];
+            out.take(cap);
+            char *o = out.p;
             F.s_min[sl] = (long)T.names.size() - 1; F.s_max[sl] = 0; F.s_sum[sl] = 0;
-            char line[256];
-            std::string cells;
-            for (size_t i = r0 + nr * sl / nfmt; i < r0 + nr * (sl + 1) / nfmt; i++) {
+            // gamma = hits / (length - k + 1): nearly every read of a file has the same length, so the text of
+            // hits / den is kept per hits value for the last den seen
+            int64_t memo_den = -1;
+            std::vector<std::array<char, 16>> memo;          // [0] = length, text from [1]
+            for (size_t i = i0; i < i1; i++) {
                 const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
                 const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
-                size_t nl = R.name_e[i] - R.name_s[i];
+                size_t nl = RI.name_e[i] - RI.name_s[i];
                 if (nl >= OBJECTNAMEMAX) nl = OBJECTNAMEMAX - 1;
-                out.append((const char *)map + R.name_s[i], nl);
-                const uint32_t norm = (uint32_t)(paired ? R.len[i] - NBN : R.len[i]);     // ITYPE objectNorm
-                const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
-                double delta = (double)(best + s_best);
-                delta = (delta < 0.001) ? 0 : ((double)best) / delta;
-                const char *assign = ibest < T.names.size() ? T.names[ibest].c_str() : "NA";
+                std::memcpy(o, text + RI.name_s[i], nl); o += nl;
+                const uint32_t norm = (uint32_t)(paired ? RI.len[i] - NBN : RI.len[i]);     // ITYPE objectNorm
                 if (opt.ext) {
                     // all scores, zeros for the targets not hit (reference :2006-2026)
                     const uint16_t *row = rows + (i - r0) * row_len;
-                    cells.clear();
                     size_t w = 0;
                     for (uint32_t h = 0; h < row[0]; h++) {
                         const size_t t = row[1 + 2 * h];
-                        for (; w < t; w++) cells += ",0";
-                        cells += ","; cells += std::to_string(row[2 + 2 * h]);
+                        for (; w < t; w++) { *o++ = ','; *o++ = '0'; }
+                        *o++ = ',';
+                        o += fmt_u32(o, row[2 + 2 * h]);
                         w++;
                     }
-                    for (; w < T.names.size() - 1; w++) cells += ",0";
-                    out += cells;
+                    for (; w < T.names.size() - 1; w++) { *o++ = ','; *o++ = '0'; }
                     F.s_max[sl] = std::max<long>(F.s_max[sl], row[0]); F.s_min[sl] = std::min<long>(F.s_min[sl], row[0]); F.s_sum[sl] += row[0];
                 }
                 // ",%g," gamma, assignment, ",%u,%g\n" best, confidence -- the two ratios without printf
                 // where format.hpp covers them (it declines the odd cases: reads shorter than k, ties)
-                char *o = line;
                 *o++ = ',';
                 const int64_t den = (int64_t)norm - (int64_t)opt.k + 1;
-                int m = den > 0 ? fmt_ratio_g(o, total, (uint64_t)den) : 0;
-                if (!m) m = std::snprintf(o, 64, "%g", gamma);
-                o += m;
+                if (den > 0 && den <= 4096 && total <= (uint64_t)den) {
+                    if (den != memo_den) { memo.assign((size_t)den + 1, std::array<char, 16>{}); memo_den = den; }
+                    std::array<char, 16> &mm = memo[total];
+                    if (!mm[0]) {
+                        char tmp[64];
+                        int m = fmt_ratio_g(tmp, total, (uint64_t)den);
+                        if (!m) m = std::snprintf(tmp, sizeof tmp, "%g", (double)total / (((double)norm - (double)opt.k) + 1.0));
+                        if (m > 15) m = 0;          // (never: six digits and an exponent)
+                        mm[0] = (char)m;
+                        std::memcpy(&mm[1], tmp, (size_t)m);
+                    }
+                    if (mm[0]) { std::memcpy(o, &mm[1], 15); o += mm[0]; }
+                    else o += std::snprintf(o, 64, "%g", (double)total / (((double)norm - (double)opt.k) + 1.0));
+                } else {
+                    const double gamma = (double)total / (((double)norm - (double)opt.k) + 1.0);
+                    int m = den > 0 ? fmt_ratio_g(o, total, (uint64_t)den) : 0;
+                    if (!m) m = std::snprintf(o, 64, "%g", gamma);
+                    o += m;
+                }
                 *o++ = ',';
-                out.append(line, (size_t)(o - line));
-                out += assign;
-                o = line;
+                if (ibest < T.names.size()) { const std::string &nm = T.names[ibest]; std::memcpy(o, nm.data(), nm.size()); o += nm.size(); }
+                else { *o++ = 'N'; *o++ = 'A'; }
                 *o++ = ',';
                 o += fmt_u32(o, best);
                 *o++ = ',';
-                m = fmt_ratio_g(o, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
-                if (!m) m = std::snprintf(o, 64, "%g", delta);
+                int m = fmt_ratio_g(o, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
+                if (!m) {
+                    double delta = (double)(best + s_best);
+                    delta = (delta < 0.001) ? 0 : ((double)best) / delta;
+                    m = std::snprintf(o, 64, "%g", delta);
+                }
                 o += m;
                 *o++ = '\n';
-                out.append(line, (size_t)(o - line));
             }
+            out.n = (size_t)(o - out.p);
         };
-        // results of batch b are on the host -> its slices go to the pool
-        auto launch_format = [&](size_t b) {
-            { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return submitted[b] != 0; }); }
+        // results of batch b are on the host -> its slices go to the pool; false: the streamed attempt was given up
+        auto launch_format = [&](size_t b) -> bool {
+            {
+                std::unique_lock<std::mutex> lk(done_mu);
+                done_cv.wait(lk, [&]() { return B[b].submitted; });
+                if (gave_up) return false;
+            }
             mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
             uint16_t *fin, *rows;
             mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, &fin, &rows);
             Formatted &F = fmt[b];
-            F.slice.assign(nfmt, std::string()); F.s_min.assign(nfmt, 0); F.s_max.assign(nfmt, 0); F.s_sum.assign(nfmt, 0);
+            F.slice.reset(new Text[nfmt]); F.s_min.assign(nfmt, 0); F.s_max.assign(nfmt, 0); F.s_sum.assign(nfmt, 0);
             F.left = nfmt;
             for (int sl = 0; sl < nfmt; sl++)
                 pool.run([&, b, sl, fin, rows]() {
@@ -409,61 +532,74 @@ struct Classifier {
                     { std::lock_guard<std::mutex> lk(done_mu); fmt[b].left--; }
                     done_cv.notify_all();
                 });
+            return true;
         };
-        launch_format(0);
-        for (size_t b = 0; b < nbatch; b++) {
-            if (b + 1 < nbatch) launch_format(b + 1);           // batch b+1 is formatted while batch b is written
+        size_t n_done = 0;
+        bool ok = launch_format(0);
+        for (size_t b = 0; ok && b < nbatch; b++) {
+            if (b + 1 < nbatch && !launch_format(b + 1)) { ok = false; }   // batch b+1 is formatted while batch b is written
             { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return fmt[b].left == 0; }); }
+            if (!ok) break;
             if (b + nbuf < nbatch) enqueue_pack(b + nbuf);      // this batch's buffers are free again
             Formatted &F = fmt[b];
-            const size_t nr = first[b + 1] - first[b];
+            const size_t nr = B[b].n;
+            n_done += nr;
             for (int sl = 0; sl < nfmt; sl++) {
                 const uint64_t at = file_off;
-                file_off += F.slice[sl].size();
+                file_off += F.slice[sl].n;
                 if (opt.ext && nr) { nz_max = std::max(nz_max, F.s_max[sl]); nz_min = std::min(nz_min, F.s_min[sl]); nz_sum += F.s_sum[sl]; }
-                if (F.slice[sl].empty()) continue;
+                if (F.slice[sl].n == 0) { F.slice[sl].drop(); continue; }
                 pool.run([&, b, sl, at]() {
-                    std::string &str = fmt[b].slice[sl];
-                    const char *p = str.data();
-                    size_t left = str.size();
+                    Text &str = fmt[b].slice[sl];
+                    const char *p = str.p;
+                    size_t left = str.n;
                     uint64_t off = at;
                     while (left) {
                         const ssize_t w = ::pwrite(fd, p, left, (off_t)off);
                         if (w <= 0) die(std::string("Failed to write ") + csv, -1);
                         p += w; left -= (size_t)w; off += (uint64_t)w;
                     }
-                    std::string().swap(str);
+                    str.drop();
                 });
             }
+            if (streamed) B[b].own = ReadIndex();              // this range's index is not needed any more
         }
         pool.finish();
+        if (!ok) {
+            // a byte range holds more than the guessed buffers take: start over with the whole-file plan
+            mc_group_sync(grp);
+            mc_group_free_batches(grp);
+            std::fclose(fout);
+            if (opt.verbose) std::cerr << "streamed ingest given up (a range of the file exceeds the guessed buffers); indexing the whole file\n";
+            return false;
+        }
+        n_objects = n_done;
         if (opt.dump) {
             FILE *dump = std::fopen(opt.dump, "wb");
             for (size_t b = 0; dump && b < nbatch; b++) {           // (nbuf == nbatch when dumping)
                 uint32_t *ptr; uint16_t *con;
                 mc_group_batch_buffers(grp, (uint32_t)b, &ptr, &con, nullptr, nullptr);
-                const uint64_t n = first[b + 1] - first[b], c = ncon[b];
+                const uint64_t n = B[b].n, c = B[b].ncon;
                 std::fwrite(&n, 8, 1, dump); std::fwrite(&c, 8, 1, dump);
                 std::fwrite(ptr, 4, n + 1, dump); std::fwrite(con, 2, c, dump);
             }
             if (dump) std::fclose(dump);
         }
         std::fclose(fout);
-        if (opt.verbose)
-            std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "
-                      << now() - ts2 << " s\n";
+        if (opt.verbose) {
+            if (streamed)
+                std::cerr << "timing: streamed (" << nbatch << " byte ranges: index | pack+submit | wait+format+write, all overlapped) "
+                          << now() - ts0 << " s\n";
+            else
+                std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "
+                          << now() - ts2 << " s\n";
+        }
         std::cerr << "Done." << std::endl;
         if (opt.ext && n_objects)
             std::cerr << "MIN targets: " << nz_min << ", MAX targets: " << nz_max << ", AVG targets: "
                       << (float)nz_sum / n_objects << "\n";
         mc_group_free_batches(grp);
-
-        gettimeofday(&t1, nullptr);
-        const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
-        char buf[256];
-        std::snprintf(buf, sizeof buf, "Done in %.1fs (%zu reads/min, %zu reads)\n", diff,
-                      (size_t)(((double)n_objects) / diff * 60.0), n_objects);
-        std::cerr << buf << "Results: " << csv << "\n";
+        return true;
     }
 
     static bool looks_like_sequence_file(const char *path)

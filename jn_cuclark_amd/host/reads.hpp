@@ -30,6 +30,11 @@ public:
     Column(const Column &) = delete;
     Column &operator=(const Column &) = delete;
     Column(Column &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    Column &operator=(Column &&o) noexcept
+    {
+        if (this != &o) { std::free(p_); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+        return *this;
+    }
     ~Column() { std::free(p_); }
     size_t size() const { return n_; }
     uint64_t &operator[](size_t i) { return p_[i]; }
@@ -121,9 +126,105 @@ inline bool index_reads_with(const uint8_t *t, size_t nb, ReadIndex &R, std::str
     return false;
 }
 
+#ifdef MC_HOST_X86
+// FASTQ in ONE sweep over the newline bitmaps of 64-byte blocks: the same records as index_reads_with
+// (a record is four lines; the byte where its '@' should be is skipped unseen; the name ends at the first
+// space/tab/newline BEHIND its first byte, so the line of an empty name does not end the header) without a
+// call per line -- half the time per record.  The last partial block and a file that ends inside a record
+// go through the same state machine with the end of the text standing in for the missing newlines.
+// first separator behind `from`, searched up to `limit` (a newline position, or nb: then nb when there is none)
+__attribute__((target("avx2")))
+inline size_t name_end_avx2(const uint8_t *t, size_t nb, size_t from, size_t limit)
+{
+    const __m256i nl = _mm256_set1_epi8(10), sp = _mm256_set1_epi8(' '), tab = _mm256_set1_epi8('\t');
+    size_t i = from + 1;
+    while (i + 32 <= nb && i <= limit) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(t + i));
+        const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, nl), _mm256_cmpeq_epi8(v, sp)), _mm256_cmpeq_epi8(v, tab)));
+        if (m) return i + (size_t)__builtin_ctz(m);
+        i += 32;
+    }
+    for (; i < nb; i++) if (is_sep(t[i])) return i;
+    return nb;
+}
+
+__attribute__((target("avx2")))
+inline void index_fastq_avx2(const uint8_t *t, size_t nb, ReadIndex &R)
+{
+    {
+        const size_t guess = nb / 200 + 16;
+        R.name_s.reserve(guess); R.name_e.reserve(guess); R.spos.reserve(guess); R.epos.reserve(guess); R.len.reserve(guess);
+    }
+    const __m256i nl = _mm256_set1_epi8(10);
+    auto name_end = [&](size_t from, size_t limit) -> size_t { return name_end_avx2(t, nb, from, limit); };
+    int line = 0;                 // 0 header, 1 sequence, 2 '+', 3 quality
+    size_t ls = 0;                // start of the current line
+    size_t name_s = 1;
+    bool open = true;             // a record has been started and its header is not complete yet
+    auto at_newline = [&](size_t pos) {
+        switch (line) {
+        case 0:
+            if (pos <= name_s) return;                       // the name's first byte is never a separator: the header goes on
+            R.name_s.push_back(name_s);
+            R.name_e.push_back(name_end(name_s, pos));
+            open = false;
+            break;
+        case 1:
+            R.spos.push_back(ls); R.epos.push_back(pos); R.len.push_back(pos - ls);
+            break;
+        default: break;
+        }
+        ls = pos + 1;
+        line = (line + 1) & 3;
+    };
+    bool stop = false;
+    size_t b = 0;
+    for (; b + 64 <= nb && !stop; b += 64) {
+        const uint32_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(t + b)), nl));
+        const uint32_t m1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(t + b + 32)), nl));
+        uint64_t m = (uint64_t)m0 | ((uint64_t)m1 << 32);
+        while (m) {
+            const size_t pos = b + (size_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const int was = line;
+            at_newline(pos);
+            if (was == 3) {                                   // a record is complete: the next one starts at ls, if there is room for one
+                if (ls + 1 >= nb) { stop = true; break; }
+                name_s = ls + 1;
+                open = true;
+            }
+        }
+    }
+    if (!stop) {
+        for (size_t i = b; i < nb && !stop; i++) {
+            if (t[i] != 10) continue;
+            const int was = line;
+            at_newline(i);
+            if (was == 3) {
+                if (ls + 1 >= nb) { stop = true; break; }
+                name_s = ls + 1;
+                open = true;
+            }
+        }
+    }
+    if (!stop) {
+        // the text ends inside a record: what index_reads_with sees when its newline search returns nb
+        if (line == 0 && open) {
+            R.name_s.push_back(name_s);
+            R.name_e.push_back(name_end(name_s, nb));
+            R.spos.push_back(nb); R.epos.push_back(nb); R.len.push_back(0);
+        } else if (line == 1) {
+            const size_t s0 = ls < nb ? ls : nb;
+            R.spos.push_back(s0); R.epos.push_back(nb); R.len.push_back(nb - s0);
+        }
+    }
+}
+#endif
+
 inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &err)
 {
 #ifdef MC_HOST_X86
+    if (cpu_has_avx2() && nb >= 64 && t[0] == '@' && !getenv("MC_HOST_GENERIC_INDEX")) { index_fastq_avx2(t, nb, R); return true; }
     if (cpu_has_avx2()) return index_reads_with<NewlineScanAvx2>(t, nb, R, err);
 #endif
     return index_reads_with<NewlineScanLibc>(t, nb, R, err);

@@ -59,8 +59,9 @@ def _expected_db(genomes, labels, k, light, gap=4, n_mask=True):
     return synth.discriminative(np.concatenate(km), np.concatenate(tg), k), uniq
 
 
-def _run(exe, args, check_gpu=True):
-    return subprocess.run([os.path.join(BIN, exe)] + args, capture_output=True, text=True, timeout=900)
+def _run(exe, args, check_gpu=True, env=None):
+    return subprocess.run([os.path.join(BIN, exe)] + args, capture_output=True, text=True, timeout=900,
+                          env=dict(os.environ, **env) if env else None)
 
 
 @pytest.mark.parametrize("variant", ["light", "full"])
@@ -197,6 +198,63 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
     flat = np.concatenate([p[:-1].astype(np.int64) + s for p, s in zip(ptrs, starts)] + [[con.size]])
     assert np.array_equal(flat, rp.astype(np.int64))
     assert "Done in" in r.stderr and "reads/min" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fastq", "fasta_70", "paired", "extended", "gives_up"])
+def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
+    """Large files are cut into byte ranges at record starts and every range is indexed, packed and submitted by
+    one task (host/main.cc classify_image, streamed plan; MC_STREAM_MIN_BYTES lowers the size it starts at).  The
+    CSV must not depend on it: FASTQ, multi-line FASTA, joined mates and the extended table against the oracle
+    with 9 ranges on 4 threads; `gives_up`: long reads first, then ten times as many short ones -- the ranges at
+    the end hold more reads than the buffers guessed from the head take, and the run starts over with the plan
+    that indexes the whole file first"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    _build()
+    k, ht = 27, 57777779
+    genomes = synth.toy_genomes(4, 5000, seed=52, shared=500)
+    labels = ["Ecoli", "Saureus", "Bsub", "Paer"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    names, seqs = mixed_fasta(genomes, k, seed=17, n=3000)
+    args = ["-T", targets, "-D", str(dbdir), "-R", str(tmp_path / "res"), "-n", "4", "-b", "9", "--verbose"]
+    paired = mode == "paired"
+    if paired:
+        m1 = [s[:100].replace(b"\n", b"") for s in seqs]
+        m2 = [s[50:150] for s in seqs]
+        nm = [n.split(b" ")[0] for n in names]
+        f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
+        f1.write_bytes(synth.fastq_text([n + b"/1" for n in nm], m1))
+        f2.write_bytes(synth.fastq_text([n + b"/2" for n in nm], m2))
+        args += ["-P", str(f1), str(f2)]
+        text = synth.fasta_text(nm, [a + b"N" + b for a, b in zip(m1, m2)])
+    elif mode == "fasta_70":
+        text = synth.fasta_text(names, seqs, width=70)
+        p = tmp_path / "reads.fa"
+        p.write_bytes(text)
+        args += ["-O", str(p)]
+    else:
+        if mode == "gives_up":
+            rng = np.random.default_rng(5)
+            long_ones = [synth.codes_to_ascii(genomes[i % 4][:4000]) for i in range(300)]
+            short_ones = [synth.codes_to_ascii(genomes[i % 4][int(s):int(s) + 40]) for i, s in enumerate(rng.integers(0, 4900, 30000))]
+            seqs = long_ones + short_ones
+            names = [b"r%d" % i for i in range(len(seqs))]
+        text = synth.fastq_text(names, seqs)
+        p = tmp_path / "reads.fq"
+        p.write_bytes(text)
+        args += ["-O", str(p)] + (["--extended"] if mode == "extended" else [])
+    r = _run("cuCLARK-l", args, env={"MC_STREAM_MIN_BYTES": "1"})
+    assert r.returncode == 0, r.stderr
+    assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up"), r.stderr
+    assert ("timing: streamed" in r.stderr) == (mode != "gives_up"), r.stderr
+    base = str(dbdir / ("db_central_k27_t4_s%d_m0_light_4.tsk" % ht))
+    want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, paired=paired, extended=mode == "extended")
+    assert open(str(tmp_path / "res.csv")).read() == want
+    assert "%d reads)" % len(seqs) in r.stderr
 
 
 STAND_IN_SCRIPT = """#!/bin/sh
@@ -373,6 +431,17 @@ def test_indexer_and_vectorised_packer_equal_the_oracle(oracle, tmp_path, fmt):
         got_rp = np.frombuffer(r.stdout, dtype=np.uint32, count=int(n) + 1, offset=16)
         got_con = np.frombuffer(r.stdout, dtype=np.uint16, count=int(c), offset=16 + 4 * (int(n) + 1))
         assert int(n) == ln.size and np.array_equal(got_rp, rp) and np.array_equal(got_con, con)
+
+
+def test_one_sweep_fastq_indexer_equals_the_line_by_line_indexer(tmp_path):
+    """host/reads.hpp index_fastq_avx2 (newline bitmaps of 64-byte blocks, one state machine) against the
+    line-by-line indexer it replaces for FASTQ, which the test above pins to the oracle's restatement of
+    src/CuCLARK_hh.hh:1476-1533: 60 000 hostile texts (soups of '@', newlines and blanks, truncated records,
+    overwritten separators), every index column equal"""
+    exe = _input_harness(tmp_path)
+    r = subprocess.run([exe, "indexfuzz", "60000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() in ("60000", "no avx2")
 
 
 def test_input_images_gzip_and_pairing(tmp_path):
