@@ -267,6 +267,11 @@ int index_end(mc_ctx *c)
                            c->mz_m, c->d_mz_lines, c->d_mz_extra);
         HIPCHK(hipGetLastError());
     }
+    if (c->mz_n_local) {      // first lines in ascending key order: what lets a lookup scan half a line (mz_match_line)
+        const int gs = (int)std::min<uint64_t>(((uint64_t)c->mz_n_local + 255) / 256, (uint64_t)c->n_cu * 32);
+        hipLaunchKernelGGL(mc::mz::mz_sort_lines_kernel, dim3(gs), dim3(256), 0, st, c->d_mz_lines, c->mz_n_local);
+        HIPCHK(hipGetLastError());
+    }
     unsigned int failed = 0;
     HIPCHK(hipMemcpyAsync(&failed, c->build.d_failed, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

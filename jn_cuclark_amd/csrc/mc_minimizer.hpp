@@ -11,10 +11,10 @@
 // hits iff its canonical value is a stored k-mer, with that k-mer's label.  Only the
 // in-HBM arrangement differs, built once at load from the same arrays:
 //
-//   K(c)    = min over the k-m+1 = MZ_MAXW (11) windows w of canonical k-mer c of key(min(w, rc(w)))
+//   K(c)    = min over the k-m+1 = MZ_MAXW (9) windows w of canonical k-mer c of key(min(w, rc(w)))
 //             (orientation-free: x and rc(x) have the same set of canonical m-mers)
 //   line(c) = mulhi(mix32(K(c)), n_lines)
-//   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, unused = all ones),
+//   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, ascending, unused = all ones last),
 //             12 labels (u16), dword30 = extra lines (bits 0-2) | spill flag (bit 3) | Bloom word
 //             over the k-mers that are not in the first line (high 16 bits), dword31 = first extra line
 //   extra lines (same shape, contiguous per line) hold what does not fit: a chain of at most MZ_EMAX
@@ -47,12 +47,14 @@ static constexpr uint32_t MZ_HDR_SEG_SHIFT = 3u, MZ_HDR_SEG_MASK = 31u;
 static constexpr uint32_t MZ_SEG_LOAD = 9u;          // k-mers aimed at per segment of MZ_EMAX * MZ_CAP = 36 slots (P(overflow) ~ 1e-12)
 static constexpr uint64_t MZ_EMPTY = ~0ull;
 #ifndef MC_MZ_MAXW
-#define MC_MZ_MAXW 11
+#define MC_MZ_MAXW 9
 #endif
 // windows per k-mer: w = k - m + 1, odd (the window is read in 16-byte pairs).  Measured on the headline
-// workload (k = 31): w = 7 / 9 / 11 / 13 / 15 / 17 -> 1141 / 1229 / 1231 / 1167 / 748 / 101 Mreads/s: fewer
+// workload (k = 31) in round 1: w = 7 / 9 / 11 / 13 / 15 / 17 -> 1141 / 1229 / 1231 / 1167 / 748 / 101 Mreads/s: fewer
 // windows mean more lines per read (density 2/(w+1)) but smaller minimizer groups and a larger minimizer
-// space (4^m): past w = 13 unrelated minimizers crowd the lines.
+// space (4^m): past w = 13 unrelated minimizers crowd the lines.  Round 2: with w = 9 the 128 positions of a
+// step hold the 120 k-mers of a 150 bp read AND the 8 m-mers behind the last one, so the tail code of the
+// kernel never runs for reads up to 150 bp: 9 / 11 windows -> 1450 / 1360 Mreads/s (genome-shaped table 1165 / 1117).
 static constexpr int MZ_MAXW = MC_MZ_MAXW;
 static_assert(MZ_MAXW % 2 == 1 && MZ_MAXW >= 3 && MZ_MAXW <= 17, "window count");
 #ifndef MC_MZ_NS
@@ -66,10 +68,10 @@ static constexpr int MZ_RUNS = MC_MZ_RUNS;    // runs (distinct lines) fetched p
 static constexpr int MZ_LSTRIDE = MZ_LINE + 16; // LDS stride of a staged line: keeps equal offsets of different
                                                 // runs on different banks (a 128-byte stride is a 9-way conflict)
 
-// minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k > 12)
+// minimizer length for a k-mer length: always w = k - m + 1 = MZ_MAXW windows (k >= MZ_MAXW)
 __host__ __device__ __forceinline__ uint32_t mmer_len(uint32_t k) { return k > (uint32_t)MZ_MAXW - 1u ? k - ((uint32_t)MZ_MAXW - 1u) : 1u; }
 
-// Ordering key of a canonical m-mer (m <= 22: below 2^44; any value works, the high word is just stirred in): t = low word of lo*C1, stirred with the
+// Ordering key of a canonical m-mer (any 64-bit value works, the high word is just stirred in): t = low word of lo*C1, stirred with the
 // high byte -- a bijection of lo for every hi, its top bits a multiplicative hash of all of lo -- then
 // 20 more bits of the product.  The 52 bits are the mantissa of a double in [1, 2): for such doubles
 // numeric order = integer order of the bit pattern, so a window minimum is ONE v_min_f64 per element
@@ -132,6 +134,12 @@ __device__ __forceinline__ uint64_t mask_lt_s(uint32_t a, uint32_t uniform_b)   
 {
     uint64_t m;
     asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_b), "v"(a));
+    return m;
+}
+__device__ __forceinline__ uint64_t mask_gt_s(uint32_t a, uint32_t uniform_b)       // a > b, b wave-uniform
+{
+    uint64_t m;
+    asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_b), "v"(a));
     return m;
 }
 __device__ __forceinline__ uint64_t mask_eq_s(uint32_t a, uint32_t uniform_b)
@@ -351,6 +359,7 @@ void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_ext
 // their arrival order): group size and rank are counted against every other entry by broadcast, so
 // nothing is sorted in memory.  The result no longer depends on the order the atomics happened to run in.
 static_assert(MZ_CHAIN_CAP <= 64, "one lane per chain entry");
+static_assert((MZ_RUNS & (MZ_RUNS - 1)) == 0, "runs per batch: a power of two (index mask in the match)");
 __global__ __launch_bounds__(256)
 void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint32_t m,
                        uint8_t *lines, uint8_t *extra_lines)
@@ -455,6 +464,56 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
     }
 }
 
+// Last build pass: the keys of every FIRST line in ascending order (unused slots = all ones come last), labels
+// moved along.  A lookup then compares its k-mer with the 7th key and scans only the half of the line that can
+// hold it (mz_match_line): 6 compares instead of 12.  It also makes the first lines independent of the order
+// the placing pass's atomics ran in.  One lane per line, odd-even transposition in registers (build time only;
+// extra lines keep their order and are scanned whole).
+__global__ __launch_bounds__(256)
+void mz_sort_lines_kernel(uint8_t *lines, uint32_t n_lines)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += stride) {
+        uint8_t *L = lines + i * MZ_LINE;
+        uint64_t key[MZ_CAP];
+        uint32_t lab[MZ_CAP];
+        {
+            const u32x4 *L4 = reinterpret_cast<const u32x4 *>(L);
+#pragma unroll
+            for (int t = 0; t < MZ_CAP / 2; t++) {
+                const u32x4 v = L4[t];
+                key[2 * t] = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+                key[2 * t + 1] = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
+            }
+            const u32x4 a = L4[6];
+            const uint2 b = *reinterpret_cast<const uint2 *>(L + 112);
+            const uint32_t w[6] = {a[0], a[1], a[2], a[3], b.x, b.y};
+#pragma unroll
+            for (int t = 0; t < MZ_CAP; t++) lab[t] = (w[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+        }
+        bool moved = false;
+#pragma unroll
+        for (int r = 0; r < MZ_CAP; r++) {
+#pragma unroll
+            for (int e = r & 1; e + 1 < MZ_CAP; e += 2) {
+                const bool sw = key[e] > key[e + 1];
+                const uint64_t ka = sw ? key[e + 1] : key[e], kb = sw ? key[e] : key[e + 1];
+                const uint32_t la = sw ? lab[e + 1] : lab[e], lb = sw ? lab[e] : lab[e + 1];
+                key[e] = ka; key[e + 1] = kb; lab[e] = la; lab[e + 1] = lb;
+                moved = moved || sw;
+            }
+        }
+        if (moved) {
+            u32x4 *L4 = reinterpret_cast<u32x4 *>(L);
+#pragma unroll
+            for (int t = 0; t < MZ_CAP / 2; t++)
+                L4[t] = u32x4{(uint32_t)key[2 * t], (uint32_t)(key[2 * t] >> 32), (uint32_t)key[2 * t + 1], (uint32_t)(key[2 * t + 1] >> 32)};
+            L4[6] = u32x4{lab[0] | (lab[1] << 16), lab[2] | (lab[3] << 16), lab[4] | (lab[5] << 16), lab[6] | (lab[7] << 16)};
+            *reinterpret_cast<uint2 *>(L + 112) = make_uint2(lab[8] | (lab[9] << 16), lab[10] | (lab[11] << 16));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // query
 // ---------------------------------------------------------------------------
@@ -474,28 +533,56 @@ enum { MZ_ALL = 0,             // the whole table
                                // (CuClarkDB.cu:552-559, :1212-1214): every shard fetches nearly every line
        MZ_LINES = 2 };         // k-mers of a LINE range: a shard fetches, matches and scores 1/G of the runs
 
-// One lane against one 128-byte line parked in LDS.  All key loads are issued before the
-// first compare (twelve dependent LDS round trips otherwise); the compares are one
-// v_cmp_eq_u64 each and the label is read only by lanes that matched.
-__device__ __forceinline__ bool mz_match_line(const uint8_t *line, uint64_t c, uint32_t &label,
-                                              uint32_t &hdr, uint32_t &extra_base)
+// One lane against one 128-byte line parked in LDS.  The keys of a first line are in ascending order
+// (mz_sort_lines_kernel; unused slots = all ones last), so the 7th key says which half of the line can hold
+// the k-mer: 6 compares instead of 12, 3 wide LDS reads instead of 6, for one more LDS round trip -- the 7th
+// key and the header of BOTH positions of a lane are read before either half (mz_line_head).  The label is
+// read only by lanes that matched.
+struct MzHead { uint64_t pivot; uint32_t hdr, extra_base; };
+__device__ __forceinline__ MzHead mz_line_head(const uint8_t *line)
+{
+    MzHead h;
+    h.pivot = *reinterpret_cast<const uint64_t *>(line + 8 * (MZ_CAP / 2));
+    const uint2 tail = *reinterpret_cast<const uint2 *>(line + MZ_LINE - 8);      // header, extra base
+    h.hdr = tail.x;
+    h.extra_base = tail.y;
+    return h;
+}
+// slot of the line that holds c, MZ_CAP when none does
+__device__ __forceinline__ uint32_t mz_match_line(const uint8_t *line, uint64_t pivot, uint64_t c)
+{
+    const uint32_t half = c >= pivot ? (uint32_t)(MZ_CAP / 2) : 0u;               // first slot of the half
+    const u32x4 *L4 = reinterpret_cast<const u32x4 *>(line + 8u * half);
+    u32x4 kv[MZ_CAP / 4];
+#pragma unroll
+    for (int t = 0; t < MZ_CAP / 4; t++) kv[t] = L4[t];
+    uint32_t at = (uint32_t)MZ_CAP - half;              // "none" once the half is added
+#pragma unroll
+    for (int e = 0; e < MZ_CAP / 2; e++) {
+        const uint64_t key = (uint64_t)kv[e >> 1][2 * (e & 1)] | ((uint64_t)kv[e >> 1][2 * (e & 1) + 1] << 32);
+        at = key == c ? (uint32_t)e : at;
+    }
+    return at + half;
+}
+__device__ __forceinline__ uint32_t mz_line_label(const uint8_t *line, uint32_t slot)
+{
+    return reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[slot];
+}
+
+// an extra line parked in LDS: all 12 slots (extra lines keep the order they were filled in)
+__device__ __forceinline__ uint32_t mz_match_full(const uint8_t *line, uint64_t c)
 {
     const u32x4 *L4 = reinterpret_cast<const u32x4 *>(line);
     u32x4 kv[MZ_CAP / 2];
 #pragma unroll
     for (int t = 0; t < MZ_CAP / 2; t++) kv[t] = L4[t];
-    const uint2 tail = *reinterpret_cast<const uint2 *>(line + MZ_LINE - 8);      // header, extra base
-    hdr = tail.x;
-    extra_base = tail.y;
     uint32_t at = MZ_CAP;
 #pragma unroll
     for (int e = 0; e < MZ_CAP; e++) {
         const uint64_t key = (uint64_t)kv[e >> 1][2 * (e & 1)] | ((uint64_t)kv[e >> 1][2 * (e & 1) + 1] << 32);
         at = key == c ? (uint32_t)e : at;
     }
-    const bool hit = at != (uint32_t)MZ_CAP;
-    if (hit) label = reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[at];
-    return hit;
+    return at;
 }
 
 // Occupancy is what this kernel lives on (measured on the headline workload, after the register
@@ -515,7 +602,10 @@ static constexpr int MZ_LDS_SLICE = (MZ_STAGE_CON + 16) * 2;
 static constexpr int MZ_LDS_RUNLINE = MZ_LDS_SLICE;
 static constexpr int MZ_LDS_LINES = MZ_LDS_RUNLINE + MZ_RUNS * 4;
 static constexpr int MZ_LDS_KEYS_BYTES = (64 * MZ_NS + MZ_MAXW + 3) * 8;
-static constexpr int MZ_LDS_WAVE = MZ_LDS_LINES + (MZ_RUNS * MZ_LSTRIDE > MZ_LDS_KEYS_BYTES ? MZ_RUNS * MZ_LSTRIDE : MZ_LDS_KEYS_BYTES);
+static constexpr int MZ_LDS_RDPTR = MZ_LDS_LINES + (MZ_RUNS * MZ_LSTRIDE > MZ_LDS_KEYS_BYTES ? MZ_RUNS * MZ_LSTRIDE : MZ_LDS_KEYS_BYTES);
+// container offsets of the group's reads (GROUP_READS + 1 of them): read from here inside the read loop, so that the
+// register they are loaded into does not have to live through it
+static constexpr int MZ_LDS_WAVE = MZ_LDS_RDPTR + ((GROUP_READS + 1) * 4 + 15) / 16 * 16;
 static_assert(MZ_LDS_LINES % 16 == 0 && MZ_LDS_WAVE % 16 == 0, "16-byte aligned LDS regions");
 // SHARD: MZ_ALL / MZ_BUCKETS / MZ_LINES (separate instantiations keep the divider and the ranges
 // out of the unsharded kernel's scalar registers).
@@ -533,6 +623,7 @@ void mz_query_kernel(const MzArgs A)
     uint32_t *runline = reinterpret_cast<uint32_t *>(s_mem[wave] + MZ_LDS_RUNLINE);
     uint8_t *linebuf = s_mem[wave] + MZ_LDS_LINES;
     uint64_t *keyv = reinterpret_cast<uint64_t *>(linebuf);     // aliases the parked lines (see above)
+    uint32_t *rdptr = reinterpret_cast<uint32_t *>(s_mem[wave] + MZ_LDS_RDPTR);
 
     const uint32_t k = a.k, m = A.m;
     constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - (MZ_MAXW - 1) (mmer_len)
@@ -554,8 +645,10 @@ void mz_query_kernel(const MzArgs A)
         uint32_t ptr_v = 0;
         {
             const uint32_t lg = opaque(lane);
-            if (lg <= nr) ptr_v = a.reads_ptr[r0 + lg];
+            if (lg <= nr) { ptr_v = a.reads_ptr[r0 + lg]; rdptr[lg] = ptr_v; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // The group is staged into the wave's LDS slice in as few pieces as fit: usually all
         // 16 reads at once; long reads (2 x 250 bp pairs, contigs) in smaller pieces; a single
         // read larger than the slice is read from global memory.
@@ -618,8 +711,8 @@ void mz_query_kernel(const MzArgs A)
         };
 
         for (uint32_t ri = rs; ri < re; ri++) {
-            const uint32_t beg = lane_bcast(ptr_v, ri);
-            uint32_t end = lane_bcast(ptr_v, ri + 1u);
+            const uint32_t beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)rdptr[ri]);      // same address in every lane
+            uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)rdptr[ri + 1u]);
             if (end > n_con) end = n_con;
             uint32_t acc_t = 0xFFFFFFFFu, acc_c = 0, n_acc = 0;
 
@@ -640,6 +733,7 @@ void mz_query_kernel(const MzArgs A)
                     bool     active[MZ_NS], leader[MZ_NS];
                     uint64_t c[MZ_NS];
                     uint32_t line[MZ_NS], run[MZ_NS];
+                    uint64_t own[MZ_NS];           // lanes whose position holds a k-mer this context answers for
                     const bool last_step = base + 64u * MZ_NS >= nk;                // wave-uniform
                     // The m-mers of the part sit at positions 0 .. nm-1; the W-1 behind its last k-mer start
                     // no k-mer.  When they all fall inside this step's 64*NS positions (every read of up to
@@ -713,7 +807,7 @@ void mz_query_kernel(const MzArgs A)
                             const uint32_t ln = opaque(lane);
                             if (last_step) {
                                 const uint32_t i = ln + 1u;
-                                keyv[64 * MZ_NS + ln] = MZ_KEY_NONE;
+                                keyv[64 * MZ_NS + ln] = (uint64_t)opaque((uint32_t)(MZ_KEY_NONE >> 32)) << 32;     // (made here, not kept in registers)
                                 keyv[q + i] = mmer_key2((x_last >> (2u * (k - m - i))) & mmask, (rc_last >> (2u * i)) & mmask);
                             } else {
                                 keyv[64 * MZ_NS + ln] = mmer_key(bases_at(first, base + 64u * MZ_NS + ln, m, mmask), m);
@@ -750,6 +844,7 @@ void mz_query_kernel(const MzArgs A)
                         // second line of the lane before (DPP wave_shr:1); nothing before lane 0
                         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)line[1], 0x138, 0xf, 0xf, false);
                         const uint64_t b0 = mask_ne(line[0], prev) & own0, b1 = mask_ne(line[1], line[0]) & own1;
+                        own[0] = own0; own[1] = own1;
                         leader[0] = __builtin_amdgcn_inverse_ballot_w64(b0);
                         leader[1] = __builtin_amdgcn_inverse_ballot_w64(b1);
                         // leaders in lower lanes (v_mbcnt) = index of this lane's first run
@@ -760,12 +855,47 @@ void mz_query_kernel(const MzArgs A)
                         n_runs = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
                     }
 
-                    bool     hit[MZ_NS];
-                    uint32_t lab[MZ_NS];
-#pragma unroll
-                    for (int s = 0; s < MZ_NS; s++) { hit[s] = false; lab[s] = 0; }
+                    uint64_t hitm[MZ_NS] = {0ull, 0ull};      // lanes whose k-mer was found (lane masks: scalar registers)
+                    uint32_t lab[MZ_NS] = {0u, 0u};
                     // one batch of up to MZ_RUNS runs; ALL = the step has no more than that (nearly always):
                     // no per-lane range tests
+                    // runline[0, nb) lists lines of `base`: 8 lanes fetch one 128-byte line, MZ_RUNS/8 rounds, all
+                    // issued before use.  Rounds are skipped as a whole (scalar branch); inside a round the lane
+                    // groups past the last line re-read it (same request, no predication).  Parked in linebuf.
+                    auto fetch_lines = [&](const uint8_t *base, const uint32_t nb, auto holes_c) {
+                        constexpr bool HOLES = decltype(holes_c)::value;       // entries may be ~0: nothing to fetch
+                        u32x4 v[MZ_RUNS / 8];
+                        const uint32_t lf = opaque(lane);
+                        const uint8_t *lane_base = base + (lf & 7u) * 16u;      // this lane's 16 bytes of a line
+                        const uint32_t last = nb - 1u;
+#pragma unroll
+                        for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
+                            if (8u * rd < nb) {
+                                const uint32_t j = 8u * rd + (lf >> 3);
+#ifdef MC_MZ_DEBUG_WINDOW      // measurement builds only (WRONG results): every fetch inside a cache-resident window of lines
+                                const uint32_t rl = runline[j < last ? j : last] & (uint32_t)(MC_MZ_DEBUG_WINDOW - 1);
+#else
+                                const uint32_t rl = runline[j < last ? j : last];
+#endif
+                                const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_base + ((uint64_t)rl << 7));
+                                if constexpr (HOLES) {
+                                    v[rd] = u32x4{0u, 0u, 0u, 0u};
+                                    if (rl != 0xFFFFFFFFu) v[rd] = __builtin_nontemporal_load(src);
+                                } else {
+                                    v[rd] = __builtin_nontemporal_load(src);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
+                            if (8u * rd < nb) {
+                                const uint32_t j = 8u * rd + (lf >> 3);
+                                *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lf & 7u) * 16u) = v[rd];
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    };
                     auto batch = [&](const uint32_t rb, auto all_c) {
                         constexpr bool ALL = decltype(all_c)::value;
                         auto in_batch = [&](int s) -> bool { return ALL || (run[s] >= rb && run[s] < rb + MZ_RUNS); };
@@ -783,70 +913,89 @@ void mz_query_kernel(const MzArgs A)
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint32_t nb = n_runs - rb < (uint32_t)MZ_RUNS ? n_runs - rb : (uint32_t)MZ_RUNS;
-                        // 8 lanes fetch one 128-byte line; MZ_RUNS/8 rounds, all issued before use.
-                        // Rounds are skipped as a whole (scalar branch); inside a round the lane groups
-                        // past the last run re-read that run's line (same request, no predication).
-                        u32x4 v[MZ_RUNS / 8];
-                        const uint32_t lf = opaque(lane);
-                        const uint8_t *lane_base = A.lines + (lf & 7u) * 16u;      // this lane's 16 bytes of a line
-                        const uint32_t last = nb - 1u;
-#pragma unroll
-                        for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
-                            if (8u * rd < nb) {
-                                const uint32_t j = 8u * rd + (lf >> 3);
-                                const uint32_t rl = runline[j < last ? j : last];
-                                const u32x4 *src = reinterpret_cast<const u32x4 *>(lane_base + ((uint64_t)rl << 7));
-                                if constexpr (SHARDED) {
-                                    v[rd] = u32x4{0u, 0u, 0u, 0u};
-                                    if (rl != 0xFFFFFFFFu) v[rd] = __builtin_nontemporal_load(src);
-                                } else {
-                                    v[rd] = __builtin_nontemporal_load(src);
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int rd = 0; rd < MZ_RUNS / 8; rd++) {
-                            if (8u * rd < nb) {
-                                const uint32_t j = 8u * rd + (lf >> 3);
-                                *reinterpret_cast<u32x4 *>(linebuf + j * MZ_LSTRIDE + (lf & 7u) * 16u) = v[rd];
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                        fetch_lines(A.lines, nb, std::integral_constant<bool, SHARDED>{});
+                        // 7th key and header of both positions first, then the halves.  EVERY lane runs the match (a
+                        // lane without a k-mer reads some parked line and is masked out afterwards): no exec-mask
+                        // juggling, and who found what stays in lane masks.
+                        const uint8_t *Lm[MZ_NS];
+                        MzHead hd[MZ_NS];
 #pragma unroll
                         for (int s = 0; s < MZ_NS; s++) {
-                            if (active[s] && in_batch(s)) {
-                                const uint8_t *L = linebuf + (run[s] - rb) * MZ_LSTRIDE;
-                                uint32_t hdr, eb;
-                                hit[s] = mz_match_line(L, c[s], lab[s], hdr, eb);
-                                // rare: lines beyond the first (Bloom bits are set only where extra lines exist)
-                                // (a line without extra lines has an empty Bloom word: the k-mer's own bits are
-                                // computed only behind that test)
-                                if (!hit[s] && hdr >= 0x10000u && (hdr & extra_mask(c[s])) == extra_mask(c[s])) {
-                                    // this k-mer's chain of the line: the one of its 2^s chains the k-mer hashes to
-                                    // (s = 0: the only one), and the one behind it when bit 2 says that some chain
-                                    // was full
-                                    const uint32_t len = hdr & MZ_HDR_LEN;
-                                    const uint32_t extra = len << ((hdr >> 2) & 1u);
-                                    eb += seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * len;
-                                    for (uint32_t e = 0; e < extra && !hit[s]; e++) {
-                                        const uint8_t *X = A.extra + ((uint64_t)eb + e) * MZ_LINE;
-                                        u32x4 xv[MZ_CAP / 2];
+                            Lm[s] = linebuf + ((run[s] - rb) & (uint32_t)(MZ_RUNS - 1)) * MZ_LSTRIDE;
+                            hd[s] = mz_line_head(Lm[s]);
+                        }
+                        uint64_t pend[MZ_NS];                   // k-mers that missed on a line that has extra lines
 #pragma unroll
-                                        for (int t = 0; t < MZ_CAP / 2; t++) xv[t] = reinterpret_cast<const u32x4 *>(X)[t];
-                                        int at = -1;
-#pragma unroll
-                                        for (int t = 0; t < MZ_CAP; t++) {
-                                            const uint64_t key = (uint64_t)xv[t >> 1][2 * (t & 1)] | ((uint64_t)xv[t >> 1][2 * (t & 1) + 1] << 32);
-                                            if (key == c[s]) at = t;
-                                        }
-                                        if (at >= 0) { hit[s] = true; lab[s] = reinterpret_cast<const uint16_t *>(X + 8 * MZ_CAP)[at]; }
-                                    }
-                                }
-                            }
+                        for (int s = 0; s < MZ_NS; s++) {
+                            uint64_t act = SHARDED ? (uint64_t)__builtin_amdgcn_ballot_w64(active[s]) : own[s];
+                            if (!ALL) act &= mask_lt_s(run[s] - rb, (uint32_t)MZ_RUNS);
+                            const uint32_t at = mz_match_line(Lm[s], hd[s].pivot, c[s]);
+                            const uint64_t found = mask_ne(at, (uint32_t)MZ_CAP) & act;
+                            if (__builtin_amdgcn_inverse_ballot_w64(found)) lab[s] = mz_line_label(Lm[s], at);
+                            hitm[s] |= found;
+                            pend[s] = act & ~found & mask_gt_s(hd[s].hdr, 0xFFFFu);        // an empty Bloom word: no extra lines
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+                        if ((pend[0] | pend[1]) != 0) {
+                            // Rare on a clean table: lines beyond the first.  A k-mer goes on only if both its Bloom
+                            // bits are set; its chain is the one of the line's 2^s chains it hashes to (s = 0: the
+                            // only one), plus the one behind it when header bit 2 says that some chain was full.
+                            uint32_t xb[MZ_NS], xn[MZ_NS];          // first line of the k-mer's chain, lines to look at
+#pragma unroll
+                            for (int s = 0; s < MZ_NS; s++) {
+                                xb[s] = 0; xn[s] = 0;
+                                if (__builtin_amdgcn_inverse_ballot_w64(pend[s])) {
+                                    const uint32_t hdr = hd[s].hdr, xm = extra_mask(c[s]);
+                                    if ((hdr & xm) == xm) {
+                                        const uint32_t len = hdr & MZ_HDR_LEN;
+                                        xn[s] = len << ((hdr >> 2) & 1u);
+                                        xb[s] = hd[s].extra_base + seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * len;
+                                    }
+                                }
+                                pend[s] = mask_ne(xn[s], 0u);
+                            }
+                            // Round r looks at line r of each pending k-mer's chain, for both positions of every lane
+                            // at once.  The lines are fetched exactly like first lines -- the pending lookups are
+                            // numbered, publish their line, 8 lanes fetch one line, the lines are parked in LDS -- so a
+                            // step pays ONE more memory round trip however many of its k-mers go on (six 16-byte loads
+                            // per lane and position, one position after the other, before).
+                            for (uint32_t r = 0; (pend[0] | pend[1]) != 0; r++) {
+                                const uint32_t n0 = (uint32_t)__popcll(pend[0]), n = n0 + (uint32_t)__popcll(pend[1]);
+                                uint32_t job[MZ_NS];
+                                job[0] = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend[0], 0u));
+                                job[1] = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(pend[1] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend[1], 0u));
+                                uint64_t found[MZ_NS] = {0ull, 0ull};
+                                for (uint32_t ch = 0; ch < n; ch += MZ_RUNS) {
+                                    uint64_t here[MZ_NS];
+#pragma unroll
+                                    for (int s = 0; s < MZ_NS; s++) {
+                                        here[s] = pend[s] & mask_lt_s(job[s] - ch, (uint32_t)MZ_RUNS);
+                                        if (__builtin_amdgcn_inverse_ballot_w64(here[s])) runline[job[s] - ch] = xb[s] + r;
+                                    }
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                    __builtin_amdgcn_wave_barrier();
+                                    fetch_lines(A.extra, n - ch < (uint32_t)MZ_RUNS ? n - ch : (uint32_t)MZ_RUNS, std::false_type{});
+#pragma unroll
+                                    for (int s = 0; s < MZ_NS; s++) {
+                                        if (here[s] == 0) continue;
+                                        const uint8_t *X = linebuf + ((job[s] - ch) & (uint32_t)(MZ_RUNS - 1)) * MZ_LSTRIDE;
+                                        const uint32_t at = mz_match_full(X, c[s]);
+                                        const uint64_t f = mask_ne(at, (uint32_t)MZ_CAP) & here[s];
+                                        if (__builtin_amdgcn_inverse_ballot_w64(f)) lab[s] = mz_line_label(X, at);
+                                        found[s] |= f;
+                                    }
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                                // still pending: not found yet and another line in the chain
+#pragma unroll
+                                for (int s = 0; s < MZ_NS; s++) {
+                                    hitm[s] |= found[s];
+                                    pend[s] &= ~found[s] & mask_gt_s(xn[s], r + 1u);
+                                }
+                            }
+                        }
                     };
                     if (n_runs <= (uint32_t)MZ_RUNS) {
                         if (n_runs) batch(0u, std::true_type{});
@@ -858,7 +1007,7 @@ void mz_query_kernel(const MzArgs A)
                     uint64_t mm[MZ_NS];
                     uint64_t many = 0;
 #pragma unroll
-                    for (int s = 0; s < MZ_NS; s++) { mm[s] = __ballot(hit[s]); many |= mm[s]; }
+                    for (int s = 0; s < MZ_NS; s++) { mm[s] = hitm[s]; many |= mm[s]; }
                     while (many) {
                         uint32_t t = 0;
                         bool got = false;
@@ -939,9 +1088,13 @@ void mz_query_kernel(const MzArgs A)
                     o3 = k2 ? (0xFFFFu - (k2 & 0xFFFFu)) + 1u : 0u;
                     o4 = k2 >> 16;
                 }
-                const uint32_t lo = opaque(lane);
-                const uint32_t out = lo == 0u ? o0 : lo == 1u ? o1 : lo == 2u ? o2 : lo == 3u ? o3 : o4;
-                if (lo < 5u) a.final_rows[rd * 5u + lo] = (uint16_t)out;
+                // the five values are wave-uniform: packed on the scalar side and stored by lane 0 (8 + 2 bytes at a
+                // 2-byte aligned address; global memory takes unaligned stores) instead of one select chain per lane
+                if (__builtin_amdgcn_inverse_ballot_w64(1ull)) {
+                    struct __attribute__((packed, aligned(2))) Row5 { uint32_t w0, w1; uint16_t h; };
+                    *reinterpret_cast<Row5 *>(a.final_rows + rd * 5u) =
+                        Row5{(o0 & 0xFFFFu) | (o1 << 16), (o2 & 0xFFFFu) | (o3 << 16), (uint16_t)o4};
+                }
             }
         }
         };   // run_group

@@ -84,7 +84,46 @@ inline std::string db_name(const std::string &folder, unsigned k, size_t n_label
     return buf;
 }
 
-struct Occ { uint64_t r, q; uint16_t t; uint32_t w; };      // w: occurrences this entry stands for (spectrum lines carry a count)
+struct Occ { uint64_t r, q; uint16_t t; uint32_t w; uint64_t seq; };      // w: occurrences this entry stands for (spectrum lines carry a count); seq: position in the stream of all targets
+
+// --tsk: the reference also writes, per target, a text file of its target-specific k-mers (createTargetFilesNames,
+// src/CuCLARK_hh.hh:342-378, and EHashtable::SaveMultiple, src/HashTableStorage_hh.hh:282-327, called from
+// makeSpecificTargetSets :1315 BEFORE the table is sorted): "<k-mer value>\t<count>\t<k-mer>" for every k-mer seen in
+// one target only, in the order the reference's table iterates -- buckets ascending, inside a bucket in the order the
+// k-mers were first inserted.  The count is the element's: Element (full variant) adds up modulo 2^32, lElement
+// (light) is a byte that takes an addition only while the sum stays below 255 (src/dataType.hh:286-341).
+struct TskEntry { uint64_t r, q, first; uint16_t t; uint64_t count; };
+
+// src/kmersConversion.cc:88-130 IndexTovector: base 4 digits, first base first, 3 = A, 2 = C, 1 = G, 0 = T
+inline void kmer_text(uint64_t v, unsigned k, char *out)
+{
+    static const char L[4] = {'T', 'G', 'C', 'A'};
+    for (unsigned i = 0; i < k; i++) out[i] = L[(v >> (2 * (k - 1 - i))) & 3u];
+    out[k] = 0;
+}
+
+inline bool write_tsk_files(const Targets &T, const std::string &folder, unsigned k, std::vector<TskEntry> &E, std::string &err)
+{
+    // inside a bucket: insertion order (the group scan delivers quotient order)
+    std::sort(E.begin(), E.end(), [](const TskEntry &a, const TskEntry &b) { return a.r != b.r ? a.r < b.r : a.first < b.first; });
+    std::vector<FILE *> fds(T.labels.size(), nullptr);
+    for (size_t t = 0; t < T.labels.size(); t++) {
+        char name[4096];
+        // (the reference's light variant indexes an empty vector for this name, :367; the full variant's rule is used for both)
+        std::snprintf(name, sizeof name, LIGHT ? "%s/%s_k%lu_light.ht" : "%s/%s_k%lu.ht", folder.c_str(), T.labels[t].c_str(), (unsigned long)k);
+        fds[t] = std::fopen(name, "w+");
+        if (!fds[t]) { err = std::string("Failed to create ") + name; for (FILE *f : fds) if (f) std::fclose(f); return false; }
+        std::fprintf(fds[t], "#Target specific k-mers labeled %s and appearing strictly more than %lu times.\n", T.labels[t].c_str(), 0ul);
+        std::fprintf(fds[t], "#IKMER ICOUNT %lu-MER \n#\n", (unsigned long)k);
+    }
+    char text[40];
+    for (const TskEntry &e : E) {
+        kmer_text(e.r + e.q * HTSIZE, k, text);
+        std::fprintf(fds[e.t], "%llu\t%lu\t%s\n", (unsigned long long)(e.r + e.q * HTSIZE), (unsigned long)e.count, text);
+    }
+    for (FILE *f : fds) std::fclose(f);
+    return true;
+}
 
 // Forward k-mers of one target file, handed to emit(uint64_t kmer, uint32_t count).  FASTA: every window of k
 // valid bases (full variant, :1127-1180), or -- light variant -- consecutive
@@ -176,13 +215,14 @@ inline bool collect_file(const std::string &path, uint16_t target, unsigned k, u
 {
     return scan_target_file(path, k, gap, min_count, [&](uint64_t x, uint32_t w) {
         const uint64_t c = canonical(x, k);
-        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target, w});
+        out.push_back(Occ{c % HTSIZE, c / HTSIZE, target, w, (uint64_t)out.size()});
     }, nt, err);
 }
 
 // Build and write <base>.sz/.ky/.lb.  Returns the number of stored k-mers.
 inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned min_count, int key_bytes,
-                           const std::string &base, uint64_t &stored, std::string &err)
+                           const std::string &base, uint64_t &stored, std::string &err,
+                           const std::string *tsk_folder = nullptr)
 {
     std::vector<Occ> occ;
     uint64_t nt = 0;
@@ -196,8 +236,9 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
     std::sort(occ.begin(), occ.end(), [](const Occ &a, const Occ &b) {
         if (a.r != b.r) return a.r < b.r;
         if (a.q != b.q) return a.q < b.q;
-        return a.t < b.t;
+        return a.seq < b.seq;             // stream order inside a k-mer's group (what --tsk's counts and order need)
     });
+    std::vector<TskEntry> tsk;
     FILE *fs = std::fopen((base + ".sz").c_str(), "wb");
     FILE *fk = std::fopen((base + ".ky").c_str(), "wb");
     FILE *fl = std::fopen((base + ".lb").c_str(), "wb");
@@ -217,6 +258,17 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
             uint64_t count = 0;
             while (j < n && occ[j].r == occ[i].r && occ[j].q == occ[i].q) { multi |= occ[j].t != occ[i].t; count += occ[j].w; j++; }
             distinct++;
+            if (tsk_folder && !multi) {
+                uint64_t ec;
+                if (LIGHT) {                                      // lElement: Set() truncates to a byte, AddToCount() saturates
+                    uint8_t b = (uint8_t)occ[i].w;
+                    for (size_t e = i + 1; e < j; e++) b = (uint8_t)(b + ((size_t)b + occ[e].w < 255 ? occ[e].w : 0));
+                    ec = b;
+                } else {
+                    ec = count > 4294967296ull ? 4294967295ull : (count & 0xFFFFFFFFull);      // ICount: two 16-bit digits
+                }
+                tsk.push_back(TskEntry{occ[i].r, occ[i].q, occ[i].seq, occ[i].t, ec});
+            }
             if (!multi && count > min_count) {        // multiplicity 1 and count > minCount
                 uint8_t &s = szbuf[occ[i].r - b0];
                 if (s == 255) { err = "This table can not be stored on disk: Some bucket list size exceeds 255."; return false; }
@@ -232,6 +284,7 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
         std::fwrite(szbuf.data(), 1, b1 - b0, fs);
     }
     std::fclose(fs); std::fclose(fk); std::fclose(fl);
+    if (tsk_folder && !write_tsk_files(T, *tsk_folder, k, tsk, err)) return false;
     std::fprintf(stderr, "Mother Hashtable successfully built. %zu %u-mers stored.\n", distinct, k);
     std::fprintf(stderr, "%lu %u-mers successfully stored in database.\n", (unsigned long)stored, k);
     return true;

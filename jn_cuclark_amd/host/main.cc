@@ -11,8 +11,8 @@
 // -d N (0 or absent = all devices, as the reference, src/CuClarkDB.cu:146-150) goes to mc_group
 // (include/mc_group.h): N replicas when the table fits one GPU, N shards with a device-to-device
 // exchange of the per-read rows when it does not -- the reference always shards (:552-559).
-// Differences from the reference, all outside the per-read results:
-//   * --tsk (.ht dumps) is not implemented.
+// --tsk: the per-target .ht text files are written with the database (host/dbbuild.hpp); the reference's
+// recovery path that rebuilds a vanished database from them (src/CuCLARK_hh.hh:633-684) is not.
 #include "../../include/mc_api.h"
 #include "../../include/mc_group.h"
 #include "common.hpp"
@@ -154,14 +154,16 @@ struct Classifier {
         const bool present = file_readable((dbbase + ".sz").c_str()) && file_readable((dbbase + ".ky").c_str()) &&
                              file_readable((dbbase + ".lb").c_str());
         if (present) return;
+        if (opt.verbose && opt.tsk) std::cerr << "Creation of targets specific k-mers files requested " << std::endl;   // (:1914-1917)
         std::cerr << "Starting the creation of the database of targets specific " << opt.k
                   << "-mers from input files..." << std::endl;
         uint64_t stored = 0;
         std::string err;
         std::cerr << "Creating database in disk..." << std::endl;
-        const bool okb = opt.gpu_build
+        // --tsk: per-target text files of the target-specific k-mers next to the database (CPU builder only)
+        const bool okb = opt.gpu_build && !opt.tsk
             ? build_database_gpu(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err)
-            : build_database(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err);
+            : build_database(T, (unsigned)opt.k, (unsigned)opt.gap, opt.minT, key_bytes, dbbase, stored, err, opt.tsk ? &folder : nullptr);
         if (!okb) die(err, -1);
     }
 

@@ -19,6 +19,7 @@ The fixtures are data (inputs + the reference's outputs); no reference source is
 """
 import hashlib
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -223,8 +224,66 @@ def abundance_golden(tmp):
     print("abundance/: %d tables, 2 merges, 2 reports written" % len(cases))
 
 
+def tsk_golden(tmp):
+    """--tsk: the per-target text files of target-specific k-mers (createTargetFilesNames, src/CuCLARK_hh.hh:342-378;
+    EHashtable::SaveMultiple, src/HashTableStorage_hh.hh:282-327), written by the REFERENCE's host driver
+    (oracle/_ref/ref_host_mc_full = src/main.cc + src/CuCLARK_hh.hh compiled where they lie): its builder runs on the
+    CPU before any device is opened, so the run ends with "No HIP devices" after the files are on disk.  Full variant,
+    k = 31 (the chained table of 1610612741 buckets: ~40 GB for a minute); the light variant's file names index an
+    empty vector in the reference (:367) and cannot be produced.  Inputs (three small genomes: a shared block,
+    a repeat inside one genome, an N) and outputs are the fixture."""
+    import numpy as np
+    d = os.path.join(OUT, "tsk")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(2024)
+    base = "ACGT"
+    g = ["".join(base[i] for i in rng.integers(0, 4, n)) for n in (700, 650, 720)]
+    shared = g[0][100:180]
+    g[1] = g[1][:300] + shared + g[1][380:]               # in two targets: not specific
+    g[2] = g[2][:200] + g[2][50:120] + g[2][270:]         # twice in one target: count 2
+    g[0] = g[0][:400] + "N" + g[0][401:]
+    # three k-mers of ONE bucket (values v, v + HTSIZE, v + 2 HTSIZE, each its own canonical form), met in the order
+    # 2, 0, 1: the reference lists a bucket in insertion order, not in key order
+    H, k = 1610612741, 31
+    code = {"A": 3, "C": 2, "G": 1, "T": 0}
+    text = lambda v: "".join("TGCA"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+    rcv = lambda v: sum((3 - ((v >> (2 * i)) & 3)) << (2 * (k - 1 - i)) for i in range(k))
+    v = None
+    while v is None:
+        c = int(rng.integers(0, 1 << 61))
+        if all(x <= rcv(x) for x in (c, c + H, c + 2 * H)):
+            v = c
+    assert all(sum(code[ch] << (2 * (k - 1 - i)) for i, ch in enumerate(text(x))) == x for x in (v, v + H))
+    g[0] += "N" + text(v + 2 * H) + "N" + text(v) + "N" + text(v + H)
+    lines = []
+    for i, seq in enumerate(g):
+        fa = os.path.join(d, "g%d.fa" % i)
+        open(fa, "w").write(">g%d toy\n" % i + "\n".join(seq[j:j + 70] for j in range(0, len(seq), 70)) + "\n")
+        lines.append("%s\t%s\n" % (os.path.join("tests", "golden", "tsk", "g%d.fa" % i), ("T%d" % i) if i < 2 else "S9"))
+    open(os.path.join(d, "targets.txt"), "w").write("".join(lines))
+    db = os.path.join(tmp, "tskdb")
+    os.makedirs(db, exist_ok=True)
+    reads = os.path.join(tmp, "r.fa")
+    open(reads, "w").write(">r\n" + g[0][:100] + "\n")
+    r = subprocess.run([os.path.join(REF, "ref_host_mc_full"), "-k", "31", "-T", os.path.join(d, "targets.txt"), "-D", db + "/",
+                        "-O", reads, "-R", os.path.join(tmp, "res"), "--tsk"], cwd=ROOT, capture_output=True, text=True)
+    print(r.stderr[-600:])
+    got = sorted(f for f in os.listdir(db) if f.endswith(".ht"))
+    assert got, "the reference wrote no .ht files"
+    for f in got:
+        shutil.copy(os.path.join(db, f), os.path.join(d, f))
+    open(os.path.join(d, "db_sha256.txt"), "w").write("".join(
+        "%s  %s\n" % (sha(os.path.join(db, f)), f.split(".tsk")[-1]) for f in sorted(os.listdir(db)) if ".tsk." in f))
+    assert "maximum number of collisions: 3" in r.stderr, "the crafted bucket did not collide"
+    print("tsk/: %s written" % ", ".join(got))
+
+
 def main():
     full = "--full" in sys.argv
+    if "--tsk-only" in sys.argv:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            tsk_golden(tmp)
+        return
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         config0_targets(tmp)
         abundance_golden(tmp)

@@ -156,7 +156,7 @@ def test_one_minimizer_shared_by_100000_kmers_is_spread_over_hashed_chains(gpu, 
     k-mers share ONE minimizer line.  A chain is capped at 3 extra lines; the crowded line gets 2^s chains and
     a k-mer's chain is picked by a hash of the k-mer, so a lookup reads a bounded number of lines; the index
     is kept for the whole table and every lookup is still exact."""
-    k, ht, m = 21, 1000003, 11
+    k, ht, m = 21, 1000003, 13           # 9 windows per k-mer: m = k - 8 (csrc/mc_minimizer.hpp MZ_MAXW)
     rng = np.random.default_rng(7)
     # an m-mer whose key is far below anything a random window offers
     cand = rng.integers(0, 1 << (2 * m), size=200000, dtype=np.uint64)
@@ -164,10 +164,12 @@ def test_one_minimizer_shared_by_100000_kmers_is_spread_over_hashed_chains(gpu, 
     canon = np.minimum(cand, rc)
     keys = np.array([_mmer_key_model(int(c)) for c in canon[:20000]], dtype=np.uint64)
     X = int(cand[int(np.argmin(keys))])
-    # k-mers = 5 free bases | X | 5 free bases, all distinct (free part enumerated)
-    free = rng.choice(1 << 20, size=130000, replace=False).astype(np.uint64)
-    left, right = free >> np.uint64(10), free & np.uint64(1023)
-    kmers = (left << np.uint64(2 * (k - 5))) | (np.uint64(X) << np.uint64(10)) | right
+    # k-mers = o free bases | X | 8 - o free bases for every offset o = 0..8, all distinct (free part enumerated)
+    free = rng.choice(9 << 16, size=130000, replace=False).astype(np.uint64)
+    off, bits = free >> np.uint64(16), free & np.uint64(0xFFFF)
+    rbits = np.uint64(2) * (np.uint64(8) - off)                     # bits of the free bases behind X
+    left, right = bits >> rbits, bits & ((np.uint64(1) << rbits) - np.uint64(1))
+    kmers = (left << (rbits + np.uint64(2 * m))) | (np.uint64(X) << rbits) | right
     ck = np.unique(synth.canonical(kmers, k))
     stored, absent = ck[:110000], ck[110000:]
     labels = (np.arange(stored.size) % 7).astype(np.uint16)

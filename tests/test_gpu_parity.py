@@ -147,7 +147,9 @@ def test_dense_buckets_overflow_table(gpu, oracle, line, monkeypatch, index_mode
     with _open(gpu, sz, ky, lb, ht=ht, ntargets=40) as db:
         info = db.db_info()
         got = db.classify(rp, con)
-    assert (info["line_bytes"] == line or index_mode == "minimizer") and info["n_overflow_buckets"] > 0
+    # (the minimizer index spreads these random k-mers evenly: whether a line overflows there is up to the hash;
+    # its extra lines have their own tests, test_minimizer_extra_line_chains and tests/test_gpu_index.py)
+    assert index_mode == "minimizer" or (info["line_bytes"] == line and info["n_overflow_buckets"] > 0)
     assert np.array_equal(got, want)
     assert (want[:, 2] > 0).mean() > 0.45
 

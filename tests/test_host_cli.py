@@ -101,6 +101,30 @@ def test_database_build_from_targets_matches_model(oracle, tmp_path, variant):
         assert r.returncode != 0 and "No HIP devices" in r.stderr      # no silent CPU fallback
 
 
+def test_tsk_writes_the_reference_s_target_specific_kmer_files(tmp_path):
+    """--tsk (createTargetFilesNames, src/CuCLARK_hh.hh:342-378; SaveMultiple, src/HashTableStorage_hh.hh:282-327): one
+    text file per target, "<value>\\t<count>\\t<k-mer>" for every k-mer seen in that target only, in the reference
+    table's iteration order (buckets ascending; inside a bucket the order of first insertion -- the fixture plants
+    three k-mers of one bucket met in the order 2, 0, 1).  Fixtures: what the REFERENCE's host driver wrote for the
+    same three genomes (tests/golden/make_golden.py tsk_golden), plus the sha256 of its .sz/.ky/.lb.  The builder runs
+    before any device is opened, so this needs no GPU (without one the run then stops with "No HIP devices")."""
+    import hashlib
+    _build()
+    gold = os.path.join(ROOT, "tests", "golden", "tsk")
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    r = subprocess.run([os.path.join(BIN, "cuCLARK"), "-k", "31", "-T", os.path.join(gold, "targets.txt"), "-D", str(dbdir) + "/",
+                        "-O", os.path.join(gold, "g0.fa"), "-R", str(tmp_path / "res"), "--tsk", "--verbose"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert "Creation of targets specific k-mers files requested" in r.stderr
+    for name in ("T0_k31.ht", "T1_k31.ht", "S9_k31.ht"):
+        assert open(str(dbdir / name), "rb").read() == open(os.path.join(gold, name), "rb").read(), name
+    want = dict(l.split()[::-1] for l in open(os.path.join(gold, "db_sha256.txt")))
+    base = str(dbdir / "db_central_k31_t3_s1610612741_m0.tsk")
+    for ext, digest in want.items():
+        assert hashlib.sha256(open(base + ext, "rb").read()).hexdigest() == digest, ext
+
+
 def test_cli_errors_match_reference_messages(tmp_path):
     _build()
     r = _run("cuCLARK", ["-k", "40", "-T", "x", "-D", "y", "-O", "z", "-R", "w"])
