@@ -272,6 +272,11 @@ int index_end(mc_ctx *c)
         hipLaunchKernelGGL(mc::mz::mz_sort_lines_kernel, dim3(gs), dim3(256), 0, st, c->d_mz_lines, c->mz_n_local);
         HIPCHK(hipGetLastError());
     }
+    if (c->build.n_extra && c->build.n_extra < 0xFFFFFFFFull) {      // extra lines too, each on its own
+        const int gs = (int)std::min<uint64_t>((c->build.n_extra + 255) / 256, (uint64_t)c->n_cu * 32);
+        hipLaunchKernelGGL(mc::mz::mz_sort_lines_kernel, dim3(gs), dim3(256), 0, st, c->d_mz_extra, (uint32_t)c->build.n_extra);
+        HIPCHK(hipGetLastError());
+    }
     unsigned int failed = 0;
     HIPCHK(hipMemcpyAsync(&failed, c->build.d_failed, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

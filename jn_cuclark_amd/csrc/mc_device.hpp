@@ -158,10 +158,11 @@ __host__ __device__ __forceinline__ uint32_t sat_u16(uint32_t c) { return c > 0x
 // with v_bfrev_b32 instead of five swap rounds.
 __device__ __forceinline__ uint64_t revcomp(uint64_t x, uint32_t k)
 {
-    // bit reversal turns each 2-bit code around as well: swap the bits of every pair back (v_bfi per half)
-    const uint32_t lo = __brev((uint32_t)(~x >> 32)), hi = __brev((uint32_t)~x);     // halves trade places
-    const uint32_t slo = ((lo >> 1) & 0x55555555u) | ((lo << 1) & 0xAAAAAAAAu);
-    const uint32_t shi = ((hi >> 1) & 0x55555555u) | ((hi << 1) & 0xAAAAAAAAu);
+    // bit reversal turns each 2-bit code around as well: swap the bits of every pair back; the complement is taken in
+    // the same three-input operation as that swap (one v_bitop3 per half instead of v_bfi + v_not)
+    const uint32_t lo = __brev((uint32_t)(x >> 32)), hi = __brev((uint32_t)x);     // halves trade places
+    const uint32_t slo = ~(((lo >> 1) & 0x55555555u) | ((lo << 1) & 0xAAAAAAAAu));
+    const uint32_t shi = ~(((hi >> 1) & 0x55555555u) | ((hi << 1) & 0xAAAAAAAAu));
     return (((uint64_t)shi << 32) | slo) >> (64u - 2u * k);
 }
 

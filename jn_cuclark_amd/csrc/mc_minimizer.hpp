@@ -105,10 +105,25 @@ __device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b)
     return __builtin_bit_cast(uint64_t, r);
 }
 
-// the same from the m-mer and its reverse complement when both are at hand
+// Smaller of two values below 2^62 in ONE instruction: such bit patterns are non-negative doubles that are never
+// NaN or infinite (exponent field at most 0x3FF), and for those numeric order = integer order (f64 denormals are
+// kept in HIP's default float mode).  A 64-bit compare and two selects otherwise.
+#ifndef MC_MZ_F64_MIN
+#define MC_MZ_F64_MIN 1
+#endif
+__device__ __forceinline__ uint64_t min_below_2_62(uint64_t a, uint64_t b)
+{
+#if MC_MZ_F64_MIN
+    return key_min(a, b);
+#else
+    return a < b ? a : b;
+#endif
+}
+
+// the same from the m-mer and its reverse complement when both are at hand (m-mers are below 2^48)
 __device__ __forceinline__ uint64_t mmer_key2(uint64_t w, uint64_t rcw)
 {
-    return key_of_canonical(w < rcw ? w : rcw);
+    return key_of_canonical(min_below_2_62(w, rcw));
 }
 
 // A copy of a per-lane value the compiler cannot trace back: what is derived from it is computed
@@ -464,11 +479,10 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
     }
 }
 
-// Last build pass: the keys of every FIRST line in ascending order (unused slots = all ones come last), labels
-// moved along.  A lookup then compares its k-mer with the 7th key and scans only the half of the line that can
+// Last build pass: the keys of every line (first lines and extra lines, each on its own) in ascending order (unused
+// slots = all ones come last), labels moved along.  A lookup then compares its k-mer with the 7th key and scans only the half of the line that can
 // hold it (mz_match_line): 6 compares instead of 12.  It also makes the first lines independent of the order
-// the placing pass's atomics ran in.  One lane per line, odd-even transposition in registers (build time only;
-// extra lines keep their order and are scanned whole).
+// the placing pass's atomics ran in.  One lane per line, odd-even transposition in registers (build time only).
 __global__ __launch_bounds__(256)
 void mz_sort_lines_kernel(uint8_t *lines, uint32_t n_lines)
 {
@@ -569,7 +583,10 @@ __device__ __forceinline__ uint32_t mz_line_label(const uint8_t *line, uint32_t 
     return reinterpret_cast<const uint16_t *>(line + 8 * MZ_CAP)[slot];
 }
 
-// an extra line parked in LDS: all 12 slots (extra lines keep the order they were filled in)
+#ifndef MC_MZ_SORTED_EXTRA
+#define MC_MZ_SORTED_EXTRA 1      // extra lines are sorted like first lines (mc_api.hip index_end): half-line scan there too
+#endif
+// an extra line parked in LDS, all 12 slots (what a lookup did before extra lines were sorted as well)
 __device__ __forceinline__ uint32_t mz_match_full(const uint8_t *line, uint64_t c)
 {
     const u32x4 *L4 = reinterpret_cast<const u32x4 *>(line);
@@ -753,27 +770,38 @@ void mz_query_kernel(const MzArgs A)
                     // m-mer computes is read by no k-mer of the part (a window ends at position nm - 1).
                     if (STAGED || p0 < (tail_in_step ? nm : nk)) {
                         if constexpr (STAGED) {
-                            uint32_t j0 = first - c0a + (p0 >> 3);                    // container index in the slice
-                            if (j0 > (uint32_t)(MZ_STAGE_CON + 4)) j0 = (uint32_t)(MZ_STAGE_CON + 4);
+                            // container index in the slice.  No clamp: a position past the part's last m-mer (whose
+                            // value nobody reads) stays below 2 * MZ_STAGE_CON + 32 containers, inside this wave's LDS
+                            const uint32_t j0 = first - c0a + (p0 >> 3);
                             const uint64_t *w = reinterpret_cast<const uint64_t *>(slice) + (j0 >> 2);
                             const uint64_t wa = w[0], wb = w[1];
                             const uint32_t b = 16u * (j0 & 3u) + 2u * (p0 & 7u);      // bit offset of base p0: <= 60
                             const uint64_t top = (wa << b) | ((wb >> 1) >> (63u - b)); // 32 bases from p0
-                            const uint64_t top1 = (top << 2) | ((wb >> (62u - b)) & 3ull);   // 32 bases from p0 + 1
                             x0 = top >> (64u - 2u * k);
-                            x1 = top1 >> (64u - 2u * k);
+                            if (k < 32u) {
+                                x1 = (top >> (62u - 2u * k)) & kmask;                 // the k bases from p0 + 1 are inside `top`
+                            } else {
+                                const uint64_t top1 = (top << 2) | ((wb >> (62u - b)) & 3ull);   // 32 bases from p0 + 1
+                                x1 = top1;
+                            }
                         } else {
                             x0 = bases_at(first, p0, k, kmask);
                             x1 = bases_at(first, p0 + 1u, k, kmask);
                         }
                         rc0 = revcomp(x0, k);
-                        rc1 = (rc0 >> 2) | ((uint64_t)(3u - ((uint32_t)x1 & 3u)) << (2u * k - 2u));
+                        if (k >= 17u) {       // the complement of x1's last base lands in the high word: one shift-or
+                            const uint64_t r2 = rc0 >> 2;
+                            rc1 = ((uint64_t)((uint32_t)(r2 >> 32) | ((~(uint32_t)x1 & 3u) << (2u * k - 34u))) << 32) | (uint32_t)r2;
+                        } else {
+                            rc1 = (rc0 >> 2) | ((uint64_t)(3u - ((uint32_t)x1 & 3u)) << (2u * k - 2u));
+                        }
                         key0 = mmer_key2(x0 >> (2u * (k - m)), rc0 & mmask);        // first m bases, both strands
-                        c[0] = x0 < rc0 ? x0 : rc0;
+                        // (canonical form: k = 32 values reach 2^64, everything shorter stays below 2^62)
+                        c[0] = k < 32u ? min_below_2_62(x0, rc0) : (x0 < rc0 ? x0 : rc0);
                         // also right for the lane whose second position is nk (no k-mer there): the m-mer at nk
                         // lies inside the part
                         key1 = mmer_key2(x1 >> (2u * (k - m)), rc1 & mmask);
-                        c[1] = x1 < rc1 ? x1 : rc1;
+                        c[1] = k < 32u ? min_below_2_62(x1, rc1) : (x1 < rc1 ? x1 : rc1);
                         if constexpr (SHARDED) {
                             // runs are formed over ALL k-mers of the part (inpart); only the k-mers of this
                             // shard are looked up (active), and only runs with such a k-mer are fetched
@@ -980,7 +1008,11 @@ void mz_query_kernel(const MzArgs A)
                                     for (int s = 0; s < MZ_NS; s++) {
                                         if (here[s] == 0) continue;
                                         const uint8_t *X = linebuf + ((job[s] - ch) & (uint32_t)(MZ_RUNS - 1)) * MZ_LSTRIDE;
+#if MC_MZ_SORTED_EXTRA
+                                        const uint32_t at = mz_match_line(X, *reinterpret_cast<const uint64_t *>(X + 8 * (MZ_CAP / 2)), c[s]);
+#else
                                         const uint32_t at = mz_match_full(X, c[s]);
+#endif
                                         const uint64_t f = mask_ne(at, (uint32_t)MZ_CAP) & here[s];
                                         if (__builtin_amdgcn_inverse_ballot_w64(f)) lab[s] = mz_line_label(X, at);
                                         found[s] |= f;

@@ -12,7 +12,16 @@ f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $f; grep "query_kernel" $f; } > $OUT/kernel_stats_query.csv
 cp $f $OUT/all_kernel_stats.csv
 i=0
-for grp in \
+# PMC_SHORT=1: only the passes the bench line and DESIGN's per-read figures need (traffic, instruction mix, clock, DRAM requests)
+if [ -n "${PMC_SHORT:-}" ]; then
+  GROUPS_LIST=("FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" \
+    "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
+    "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM" \
+    "GRBM_GUI_ACTIVE GRBM_UTCL2_BUSY" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum")
+else
+  GROUPS_LIST=()
+fi
+for grp in "${GROUPS_LIST[@]}" \
   "FETCH_SIZE TCC_HIT_sum" \
   "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
@@ -23,6 +32,7 @@ for grp in \
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum" \
   "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_TAG_STALL_sum TCC_BUSY_sum" ; do
   i=$((i+1))
+  if [ -n "${PMC_SHORT:-}" ] && [ $i -gt ${#GROUPS_LIST[@]} ]; then break; fi
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc$i.err
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 - "$f" >> $OUT/pmc_query.txt <<'PY'
