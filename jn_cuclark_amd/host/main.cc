@@ -379,7 +379,7 @@ struct Classifier {
                 const uint32_t buf = (uint32_t)(b % nbuf);
                 uint32_t *ptr; uint16_t *con;
                 mc_check(mc_group_batch_buffers(grp, buf, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
-                X.ncon = pack_reads(X.text, *X.R, X.r0, X.r0 + X.n, (unsigned)opt.k, ptr, con);
+                X.ncon = pack_reads(X.text, *X.R, X.r0, X.r0 + X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text));
                 std::lock_guard<std::mutex> lk(submit_mu);
                 mc_check(mc_group_submit(grp, buf, X.n, X.ncon, flags), "mc_group_submit");
             }

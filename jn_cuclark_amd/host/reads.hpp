@@ -312,8 +312,9 @@ inline size_t container_bound(const ReadIndex &R, size_t r0, size_t r1, unsigned
 }
 
 // Pack reads [r0, r1) of the file image.  Returns the number of containers written.
+// `avail`: bytes that may be read from t (the rest of the file image; 0 = unknown: no loads past a read's end).
 inline size_t pack_reads(const uint8_t *t, const ReadIndex &R, size_t r0, size_t r1, unsigned k,
-                         uint32_t *ptr, uint16_t *con)
+                         uint32_t *ptr, uint16_t *con, size_t avail = 0)
 {
     const auto &ct = codes();
     size_t count = 0;
@@ -332,6 +333,11 @@ inline size_t pack_reads(const uint8_t *t, const ReadIndex &R, size_t r0, size_t
             {   // whole 32-base blocks of the run, vectorised; the scalar loop takes over at the first other byte
                 const size_t done = pack_blocks(t + i, e - i, con + count);
                 i += done; count += done / 8; plen += (uint32_t)done;
+                // what is left of a run that ends with the sequence (fewer than 32 bases): one masked block
+                const size_t rem = e - i;
+                if (rem && rem < 32 && i + 32 <= avail && pack_tail(t + i, rem, con + count)) {
+                    i = e; count += (rem + 7) / 8; plen += (uint32_t)rem;
+                }
             }
             while (i < e) {
                 const int code = ct.r[t[i]];

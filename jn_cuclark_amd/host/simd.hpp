@@ -62,6 +62,38 @@ inline size_t pack_blocks_avx2(const uint8_t *p, size_t n, uint16_t *out)
 }
 #endif
 
+// The last n < 32 bases of a run that ENDS after them (a FASTQ sequence line: 150 bp = four whole blocks and 22 bases,
+// and the byte-at-a-time loop spent more time on those 22 than the blocks on 128): the same block arithmetic on a
+// 32-byte load whose bytes behind the n-th are masked to code 0, i.e. to the zero padding of a left-aligned last
+// container.  The caller guarantees 32 readable bytes.  Returns false -- nothing written -- unless all n bytes are bases.
+__attribute__((target("avx2")))
+inline bool pack_tail_avx2(const uint8_t *p, size_t n, uint16_t *out)
+{
+    const __m256i code_tbl = _mm256_setr_epi8(0, 3, 0, 2, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0,
+                                              0, 3, 0, 2, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0);
+    const char X = (char)0xFF;
+    const __m256i char_tbl = _mm256_setr_epi8(X, 'A', X, 'C', 'T', 'U', X, 'G', X, X, X, X, X, X, X, X,
+                                              X, 'A', X, 'C', 'T', 'U', X, 'G', X, X, X, X, X, X, X, X);
+    const __m256i nib = _mm256_set1_epi8(0x0F), upper = _mm256_set1_epi8((char)0xDF);
+    const __m256i w1 = _mm256_set1_epi16(0x0104), w2 = _mm256_set1_epi32(0x00010010);
+    const __m256i idx = _mm256_setr_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                         16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p));
+    const __m256i lo = _mm256_and_si256(v, nib);
+    const __m256i ok = _mm256_cmpeq_epi8(_mm256_and_si256(v, upper), _mm256_shuffle_epi8(char_tbl, lo));
+    const uint32_t want = (uint32_t)((1ull << n) - 1ull);
+    if (((uint32_t)_mm256_movemask_epi8(ok) & want) != want) return false;
+    const __m256i keep = _mm256_cmpgt_epi8(_mm256_set1_epi8((char)n), idx);          // byte i < n
+    const __m256i codes = _mm256_and_si256(_mm256_shuffle_epi8(code_tbl, lo), keep);
+    const __m256i t1 = _mm256_maddubs_epi16(codes, w1);
+    const __m256i t2 = _mm256_madd_epi16(t1, w2);
+    const __m256i t3 = _mm256_or_si256(_mm256_slli_epi64(t2, 8), _mm256_srli_epi64(t2, 32));
+    const uint16_t c[4] = {(uint16_t)_mm256_extract_epi16(t3, 0), (uint16_t)_mm256_extract_epi16(t3, 4),
+                           (uint16_t)_mm256_extract_epi16(t3, 8), (uint16_t)_mm256_extract_epi16(t3, 12)};
+    for (size_t j = 0; j < (n + 7) / 8; j++) out[j] = c[j];
+    return true;
+}
+
 // Newline finder for the indexer: keeps the newline bitmap of the current 32-byte block, so that the
 // 4 lines of a FASTQ record cost ~10 block loads instead of four memchr calls.
 struct NewlineScanAvx2 {
@@ -106,6 +138,15 @@ struct NewlineScanLibc {
         return p ? (size_t)((const uint8_t *)p - t) : nb;
     }
 };
+
+inline bool pack_tail(const uint8_t *p, size_t n, uint16_t *out)
+{
+#ifdef MC_HOST_X86
+    if (cpu_has_avx2()) return pack_tail_avx2(p, n, out);
+#endif
+    (void)p; (void)n; (void)out;
+    return false;
+}
 
 inline size_t pack_blocks(const uint8_t *p, size_t n, uint16_t *out)
 {

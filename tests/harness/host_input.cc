@@ -37,7 +37,7 @@ int main(int argc, char **argv)
         const uint64_t n = R.size();
         std::vector<uint32_t> ptr(n + 1);
         std::vector<uint16_t> con(host::container_bound(R, 0, n, k));
-        const uint64_t c = host::pack_reads(img.data(), R, 0, n, k, ptr.data(), con.data());
+        const uint64_t c = host::pack_reads(img.data(), R, 0, n, k, ptr.data(), con.data(), img.size());
         std::fwrite(&n, 8, 1, stdout); std::fwrite(&c, 8, 1, stdout);
         std::fwrite(ptr.data(), 4, n + 1, stdout); std::fwrite(con.data(), 2, c, stdout);
         std::cerr << (host::cpu_has_avx2() ? "avx2" : "scalar") << std::endl;
