@@ -196,7 +196,8 @@ int mc_free_batches(mc_ctx *ctx);
  * `stream` is a hipStream_t (NULL = the HIP default stream).  Used by the
  * multi-GPU path (rows travel over RCCL between the calls) and by bench.py. */
 
-/* queryKernel (+ fused resultKernel when MC_F_FINAL): CuClarkDB.cu:999-1254. */
+/* queryKernel (+ fused resultKernel when MC_F_FINAL): CuClarkDB.cu:999-1254.  One batch holds at most
+ * 2^32 - 32 reads and 2^32 - 1 containers (reads_ptr is u32, as the reference's, :1034-1035): MC_EINVAL beyond. */
 int mc_query_device(mc_ctx *ctx, const uint32_t *d_reads_ptr, const uint16_t *d_containers,
                     uint64_t n_reads, uint64_t n_containers, uint32_t flags,
                     uint16_t *d_final_rows, uint16_t *d_sparse_rows, void *stream);

@@ -744,7 +744,7 @@ void mz_query_kernel(const MzArgs A)
                 for (uint32_t base = 0; base < nk; base += 64u * MZ_NS) {
                     // (1) lane l holds the two k-mers at positions base + 2l and base + 2l + 1: the second
                     //     is the first shifted by one base (no second cut from LDS, no second reverse
-                    //     complement), and their two windows share 12 of 14 m-mer keys.  Keys of the
+                    //     complement), and their two windows share W - 1 of W + 1 m-mer keys.  Keys of the
                     //     m-mers at base .. base + 64*NS + W - 2 go to LDS (m-mer p = first m bases of k-mer p).
                     static_assert(MZ_NS == 2, "two consecutive positions per lane");
                     bool     active[MZ_NS], leader[MZ_NS];
