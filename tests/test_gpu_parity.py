@@ -55,7 +55,7 @@ def test_mixed_reads_bit_exact(gpu, oracle, fmt, index_mode):
     assert (want[:, 2] > 0).sum() > 1000
 
 
-@pytest.mark.parametrize("length", [21, 22, 84, 85, 86, 148, 149, 150, 151, 277, 501, 1000])
+@pytest.mark.parametrize("length", [21, 22, 84, 85, 86, 139, 140, 141, 148, 149, 150, 151, 277, 501, 1000])
 def test_read_lengths_around_wave_boundaries(gpu, oracle, length):
     """k-mers per read around 64 / 128 (one / two wave steps) and long reads"""
     genomes, sz, ky, lb = small_db(glen=6000)
@@ -152,6 +152,27 @@ def test_dense_buckets_overflow_table(gpu, oracle, line, monkeypatch, index_mode
     assert index_mode == "minimizer" or (info["line_bytes"] == line and info["n_overflow_buckets"] > 0)
     assert np.array_equal(got, want)
     assert (want[:, 2] > 0).mean() > 0.45
+
+
+@pytest.mark.parametrize("k", [16, 17, 18])
+def test_smallest_k_of_the_minimizer_index(gpu, oracle, k, index_mode):
+    """k = 16 is the smallest k the minimizer index takes (m = k - 8 = 8); the kernel's second reverse complement has a
+    code path of its own below k = 17 (the complemented base lands in the low word).  Reads with N, lower case, short
+    parts; rows and results against the oracle."""
+    ht = 100003
+    genomes = synth.toy_genomes(4, 1500, 13, shared=100)
+    sz, ky, lb = synth.genome_db(genomes, k, ht)
+    names, seqs = mixed_fasta(genomes, k, seed=4, n=800)
+    _, rp, con = pack_with_oracle(oracle, synth.fasta_text(names, seqs, width=70), k)
+    want_rows, _ = oracle.OracleDB.from_arrays(ht, sz, ky, lb).query_rows(k, rp, con, 15)
+    with _open(gpu, sz, ky, lb, k=k, ht=ht) as db:
+        info = db.db_info()
+        got, rows = db.classify(rp, con, extended=True)
+    if index_mode == "minimizer":
+        assert info["index_kind"] == 1 and info["index_fallback"] == 0
+    assert np.array_equal(rows, want_rows)
+    assert np.array_equal(got, oracle.result_rows(want_rows))
+    assert (got[:, 2] > 0).sum() > 300
 
 
 @pytest.mark.parametrize("shards", [2, 4, 8])

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-pmc}; shift || true
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --verify 0 $*"
+ARGS="--steps ${PROF_STEPS:-3} --warmup ${PROF_WARMUP:-1} --no-cpu-baseline --no-pipelined --verify 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $f; grep "query_kernel" $f; } > $OUT/kernel_stats_query.csv
@@ -33,6 +33,7 @@ for grp in "${GROUPS_LIST[@]}" \
   "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_TAG_STALL_sum TCC_BUSY_sum" ; do
   i=$((i+1))
   if [ -n "${PMC_SHORT:-}" ] && [ $i -gt ${#GROUPS_LIST[@]} ]; then break; fi
+  if [ -n "${PMC_MAX:-}" ] && [ $i -gt ${PMC_MAX} ]; then break; fi
   rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc$i -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc$i.err
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 - "$f" >> $OUT/pmc_query.txt <<'PY'
@@ -50,4 +51,7 @@ PY
 done
 rm -rf $OUT/trace/*/*kernel_trace.csv
 cat $OUT/kernel_stats_query.csv; cat $OUT/pmc_query.txt
+# (NO_TRAFFIC=1: a profile of another workload must not replace the headline's traffic figure)
+if [ -z "${NO_TRAFFIC:-}" ]; then
 python3 tools/update_traffic.py $OUT/pmc_query.txt $OUT/bench_trace.json > $OUT/traffic.json && cp profiles/traffic.json $OUT/traffic_profiles.json
+fi
