@@ -454,6 +454,9 @@ struct Classifier {
             // hits / den is kept per hits value for the last den seen
             int64_t memo_den = -1;
             std::vector<std::array<char, 16>> memo;          // [0] = length, text from [1]
+            // confidence = best / (best + second): the text per (best, second) pair while both stay below 128
+            // (a 150 bp read has at most 120-124 hits)
+            static thread_local std::vector<std::array<char, 16>> memo2(128 * 128, std::array<char, 16>{});      // (the text depends on the pair only)
             for (size_t i = i0; i < i1; i++) {
                 const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
                 const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
@@ -504,13 +507,27 @@ struct Classifier {
                 *o++ = ',';
                 o += fmt_u32(o, best);
                 *o++ = ',';
-                int m = fmt_ratio_g(o, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
-                if (!m) {
-                    double delta = (double)(best + s_best);
-                    delta = (delta < 0.001) ? 0 : ((double)best) / delta;
-                    m = std::snprintf(o, 64, "%g", delta);
+                auto confidence = [&](char *dst) -> int {
+                    int m = fmt_ratio_g(dst, best, (uint64_t)best + s_best ? (uint64_t)best + s_best : 1u);
+                    if (!m) {
+                        double delta = (double)(best + s_best);
+                        delta = (delta < 0.001) ? 0 : ((double)best) / delta;
+                        m = std::snprintf(dst, 64, "%g", delta);
+                    }
+                    return m;
+                };
+                if (best < 128u && s_best < 128u) {
+                    std::array<char, 16> &mm = memo2[best * 128u + s_best];
+                    if (!mm[0]) {
+                        char tmp[64];
+                        const int m = confidence(tmp);
+                        if (m <= 15) { mm[0] = (char)m; std::memcpy(&mm[1], tmp, (size_t)m); }
+                    }
+                    if (mm[0]) { std::memcpy(o, &mm[1], 15); o += mm[0]; }
+                    else o += confidence(o);
+                } else {
+                    o += confidence(o);
                 }
-                o += m;
                 *o++ = '\n';
             }
             out.n = (size_t)(o - out.p);
