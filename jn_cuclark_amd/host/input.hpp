@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +68,13 @@ public:
         own_ = std::move(buf);
         data_ = own_.data(); size_ = own_.size();
     }
+    // the same for a malloc'd block (never zero-filled: the parallel mate join writes every byte itself)
+    void adopt_raw(uint8_t *p, size_t n)
+    {
+        release();
+        raw_ = p;
+        data_ = p; size_ = n;
+    }
 
 private:
     void release()
@@ -75,6 +83,7 @@ private:
         if (fd_ != -1) close(fd_);
         map_ = nullptr; fd_ = -1; map_len_ = 0; data_ = nullptr; size_ = 0; gz_ = false;
         std::vector<uint8_t>().swap(own_);
+        std::free(raw_); raw_ = nullptr;
     }
 
     static bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)
@@ -127,12 +136,13 @@ private:
     int fd_ = -1;
     bool gz_ = false;
     std::vector<uint8_t> own_;
+    uint8_t *raw_ = nullptr;
 };
 
 // FASTQ mates -> FASTA records ">id\nR1NR2" in memory (reference mergePairedFiles, src/file.cc:205-268: ids
 // must match after cutting at ' ', '/', '\t', '@'; same messages).
 inline bool merge_paired(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, std::vector<uint8_t> &out,
-                         std::string &err)
+                         std::string &err, size_t reserve_hint = 0)
 {
     struct Lines {
         const uint8_t *p, *end;
@@ -155,7 +165,7 @@ inline bool merge_paired(const uint8_t *a, size_t na, const uint8_t *b, size_t n
         s = l + i; len = e - i;
     };
     out.clear();
-    out.reserve(na / 2 + nb / 2 + 1024);
+    out.reserve(reserve_hint ? reserve_hint : na / 2 + nb / 2 + 1024);
     const uint8_t *l1, *l2;
     size_t n1, n2;
     bool first = true;
@@ -184,5 +194,15 @@ inline bool merge_paired(const uint8_t *a, size_t na, const uint8_t *b, size_t n
     }
     return true;
 }
+
+// The same join on several threads, for files of well-formed FASTQ (every record four lines, as many records in one
+// file as in the other): file 1 is cut into byte ranges at record starts, the records of every range are counted (and
+// checked: the line a record starts with begins with '@', the line two below with '+'), the matching record of file 2
+// is found from the counts of ITS ranges, and every range pair is joined into a buffer of its own; the buffers are
+// copied side by side into one block.  Whenever the files are not that regular -- a blank line, a different number of
+// records, a count that does not divide -- the sequential join above decides, messages included.  `n_threads` plain
+// threads.  The result is malloc'd: *out, *out_len (free() it).
+inline bool merge_paired_parallel(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, int n_threads,
+                                  uint8_t **out, size_t *out_len, std::string &err);
 
 } // namespace host

@@ -19,6 +19,7 @@
 #include "dbbuild.hpp"
 #include "reads.hpp"
 #include "input.hpp"
+#include "pairs.hpp"
 #include "format.hpp"
 
 #include <fcntl.h>
@@ -211,10 +212,17 @@ struct Classifier {
         InputImage a, b, joined;
         std::string err;
         if (!a.load(f1, err) || !b.load(f2, err)) { std::cerr << err << std::endl; std::exit(1); }
-        std::vector<uint8_t> buf;
-        if (!merge_paired(a.data(), a.size(), b.data(), b.size(), buf, err)) { perror(err.c_str()); std::exit(1); }   // as file.cc:220-259
-        if (buf.empty()) { std::cerr << "Failed to open " << f1 << std::endl; return; }
-        joined.adopt(std::move(buf));
+        uint8_t *buf = nullptr;
+        size_t buf_len = 0;
+        struct timeval tj0, tj1;
+        gettimeofday(&tj0, nullptr);
+        if (!merge_paired_parallel(a.data(), a.size(), b.data(), b.size(), (int)opt.cpu, &buf, &buf_len, err)) { perror(err.c_str()); std::exit(1); }   // as file.cc:220-259
+        if (buf_len == 0) { std::free(buf); std::cerr << "Failed to open " << f1 << std::endl; return; }
+        joined.adopt_raw(buf, buf_len);
+        gettimeofday(&tj1, nullptr);
+        if (opt.verbose)
+            std::cerr << "timing: mates joined in memory (" << opt.cpu << " threads) "
+                      << (tj1.tv_sec - tj0.tv_sec) + (tj1.tv_usec - tj0.tv_usec) / 1e6 << " s\n";
         run_image(joined.data(), joined.size(), result);
     }
 

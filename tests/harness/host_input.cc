@@ -6,6 +6,7 @@
 // exit code 2 + message on stderr on failure.
 #include "../../jn_cuclark_amd/host/input.hpp"
 #include "../../jn_cuclark_amd/host/reads.hpp"
+#include "../../jn_cuclark_amd/host/pairs.hpp"
 
 #include <cstdio>
 #include <iostream>
@@ -18,6 +19,16 @@ int main(int argc, char **argv)
         host::InputImage img;
         if (!img.load(argv[2], err)) { std::cerr << err << std::endl; return 2; }
         std::fwrite(img.data(), 1, img.size(), stdout);
+        return 0;
+    }
+    if (argc == 5 && std::string(argv[1]) == "pairp") {       // the join on argv[4] threads (pairs.hpp)
+        host::InputImage a, b;
+        if (!a.load(argv[2], err) || !b.load(argv[3], err)) { std::cerr << err << std::endl; return 2; }
+        uint8_t *out = nullptr;
+        size_t n = 0;
+        if (!host::merge_paired_parallel(a.data(), a.size(), b.data(), b.size(), atoi(argv[4]), &out, &n, err)) { std::cerr << err << std::endl; return 2; }
+        std::fwrite(out, 1, n, stdout);
+        std::free(out);
         return 0;
     }
     if (argc == 4 && std::string(argv[1]) == "pair") {

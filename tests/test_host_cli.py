@@ -101,6 +101,46 @@ def test_database_build_from_targets_matches_model(oracle, tmp_path, variant):
         assert r.returncode != 0 and "No HIP devices" in r.stderr      # no silent CPU fallback
 
 
+def test_parallel_mate_join_equals_the_sequential_one(tmp_path):
+    """host/pairs.hpp: paired FASTQ files joined on several threads (byte ranges of file 1 at record starts, the
+    matching record of file 2 found from record counts) against the sequential join that restates mergePairedFiles
+    (src/file.cc:205-268): a regular pair of 5 MB files (quality lines that start with '@' included), the same without
+    the final newline, and three pairs the parallel path must hand to the sequential one or fail like it -- a blank
+    line in file 1, a changed id, a truncated file 2: same bytes or the same message"""
+    exe = _input_harness(tmp_path)
+    rng = np.random.default_rng(3)
+    n = 45000
+
+    def fq(tag, L):
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, L))]
+        out = bytearray()
+        for i in range(n):
+            q = (b"@" + b"I" * (L - 1)) if i % 3 == 0 else b"I" * L
+            out += b"@r%07d/%s\n" % (i, tag) + seq[i].tobytes() + b"\n+\n" + q + b"\n"
+        return bytes(out)
+
+    a, b = fq(b"1", 100), fq(b"2", 80)
+    cut = a.index(b"@r0030000/1")
+    cases = {
+        "regular": (a, b),
+        "no_final_newline": (a, b[:-1]),
+        "blank_line": (a[:cut] + b"\n" + a[cut:], b),
+        "changed_id": (a, b.replace(b"@r0020000/2", b"@r0020001/2", 1)),
+        "truncated": (a, b[:len(b) // 2 + 7]),
+    }
+    for name, (x, y) in cases.items():
+        f1, f2 = tmp_path / (name + "_1.fq"), tmp_path / (name + "_2.fq")
+        f1.write_bytes(x)
+        f2.write_bytes(y)
+        seq = subprocess.run([exe, "pair", str(f1), str(f2)], capture_output=True, timeout=300)
+        par = subprocess.run([exe, "pairp", str(f1), str(f2), "4"], capture_output=True, timeout=300)
+        assert par.returncode == seq.returncode, name
+        assert par.stdout == seq.stdout, name
+        assert par.stderr == seq.stderr, name
+        if name in ("regular", "no_final_newline"):
+            assert seq.returncode == 0 and seq.stdout.count(b">") == n and seq.stdout.startswith(b">r0000000\n")
+
+
 def test_tsk_writes_the_reference_s_target_specific_kmer_files(tmp_path):
     """--tsk (createTargetFilesNames, src/CuCLARK_hh.hh:342-378; SaveMultiple, src/HashTableStorage_hh.hh:282-327): one
     text file per target, "<value>\\t<count>\\t<k-mer>" for every k-mer seen in that target only, in the reference
@@ -417,7 +457,7 @@ def test_gpu_database_build_is_byte_identical_to_cpu_build(tmp_path, variant):
 
 def _input_harness(tmp_path):
     exe = str(tmp_path / "host_input")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-fopenmp", "-o", exe, os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"],
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fopenmp", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"],
                    check=True)
     return exe
 

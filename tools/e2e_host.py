@@ -52,9 +52,20 @@ def main():
     rec.tofile(fq)
     print("generated %d reads (%.2f GB) in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
     exe = os.path.join(ROOT, "bin", "cuCLARK-l")
+    inputs = ["-O", fq]
+    if len(sys.argv) > 4 and sys.argv[4] == "paired":
+        # the same reads as mates: file 2 = the same records with "/2" names (ids match after the cut at '/')
+        rec2 = rec.copy()
+        rec[:, 10:12] = np.frombuffer(b"/1", dtype=np.uint8)
+        rec2[:, 10:12] = np.frombuffer(b"/2", dtype=np.uint8)
+        f1, f2 = work + "/reads_1.fq", work + "/reads_2.fq"
+        rec.tofile(f1)
+        rec2.tofile(f2)
+        inputs = ["-P", f1, f2]
+        print("paired: 2 x %.2f GB" % (os.path.getsize(f1) / 1e9), flush=True)
     for run in range(2):
         t0 = time.time()
-        r = subprocess.run([exe, "-T", work + "/targets.txt", "-D", work + "/db", "-O", fq, "-R", work + "/res",
+        r = subprocess.run([exe, "-T", work + "/targets.txt", "-D", work + "/db"] + inputs + ["-R", work + "/res",
                             "-n", threads, "-b", "32", "--verbose"], capture_output=True, text=True)
         dt = time.time() - t0
         tail = [l for l in r.stderr.split("\n") if "Done in" in l or "timing" in l]
