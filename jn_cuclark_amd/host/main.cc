@@ -205,13 +205,23 @@ struct Classifier {
         run_image(img.data(), img.size(), result);
     }
 
-    // paired FASTQ mates, joined in memory (the reference goes through a temporary FASTA file)
+    // paired FASTQ mates (the reference goes through a temporary FASTA file): classified straight from the two files
+    // when they are large and regular, joined in memory first otherwise
     void run_paired(const char *f1, const char *f2, const char *result)
     {
         std::cerr << "Classifying: " << f1 << " + " << f2 << "\n";
         InputImage a, b, joined;
         std::string err;
         if (!a.load(f1, err) || !b.load(f2, err)) { std::cerr << err << std::endl; std::exit(1); }
+        struct timeval t0;
+        gettimeofday(&t0, nullptr);
+        size_t stream_min = 8u << 20;
+        if (const char *e = getenv("MC_STREAM_MIN_BYTES")) stream_min = (size_t)std::strtoull(e, nullptr, 10);
+        if (a.size() >= stream_min && b.size() >= stream_min && !opt.dump && a.data()[0] == '@' && b.data()[0] == '@' &&
+            !getenv("MC_JOIN_MATES")) {
+            const Mates m{b.data(), b.size()};
+            if (classify_image(a.data(), a.size(), result, true, &m)) { done_line(t0, result); return; }
+        }
         uint8_t *buf = nullptr;
         size_t buf_len = 0;
         struct timeval tj0, tj1;
@@ -226,6 +236,17 @@ struct Classifier {
         run_image(joined.data(), joined.size(), result);
     }
 
+    void done_line(const struct timeval &t0, const char *result)
+    {
+        struct timeval t1;
+        gettimeofday(&t1, nullptr);
+        const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "Done in %.1fs (%zu reads/min, %zu reads)\n", diff,
+                      (size_t)(((double)n_objects) / diff * 60.0), n_objects);
+        std::cerr << buf << "Results: " << result << ".csv\n";
+    }
+
     // One batch of the file on its way through the pipeline.  Its reads are either a slice of ONE index of the
     // whole file (small files, --dump-batches, or after the streamed attempt gave up) or its own index of a
     // byte range of the file (streamed: offsets relative to `text`).
@@ -236,11 +257,50 @@ struct Classifier {
         size_t r0 = 0, n = 0;           // reads [r0, r0 + n) of *R
         size_t ncon = 0;
         bool indexed = false, submitted = false;
+        ReadIndex own2;                 // mates classified straight from their two files: the records of file 2
+        const uint8_t *text2 = nullptr;
     };
+    // file 2 of a pair, when the mates are not joined into one text first (streamed plan only)
+    struct Mates { const uint8_t *b; size_t nb; };
+
+    // the id of a FASTQ header line as mergePairedFiles cuts it (src/file.cc:230-247: leading ' ', '/', tab, '@' skipped,
+    // then up to the next of them); [line, end) = the line without its newline
+    static void mate_id(const uint8_t *t, size_t line, size_t end, size_t &s, size_t &e)
+    {
+        auto sep = [](uint8_t c) { return c == ' ' || c == '/' || c == '\t' || c == '@'; };
+        size_t i = line;
+        while (i < end && sep(t[i])) i++;
+        size_t j = i;
+        while (j < end && !sep(t[j])) j++;
+        s = i; e = j;
+    }
+    static size_t line_end(const uint8_t *t, size_t nb, size_t from)
+    {
+        const void *p = from < nb ? std::memchr(t + from, '\n', nb - from) : nullptr;
+        return p ? (size_t)((const uint8_t *)p - t) : nb;
+    }
+    // the record of file 2 whose id equals the id of file 1's record at `at1`, looked for around the same relative
+    // position of file 2 (mates come in the same order; equal read lengths put them at the same fraction exactly)
+    static bool find_mate(const uint8_t *a, size_t na, size_t at1, const uint8_t *b, size_t nb, size_t &at2)
+    {
+        size_t s1, e1;
+        mate_id(a, at1, line_end(a, na, at1), s1, e1);
+        const size_t guess = (size_t)((unsigned __int128)nb * at1 / (na ? na : 1));
+        const size_t window = 256u << 10;
+        size_t i = record_start_at_or_after(b, nb, guess > window ? guess - window : 0, true);
+        const size_t stop = std::min(nb, guess + window);
+        while (i < stop) {
+            size_t s2, e2;
+            mate_id(b, i, line_end(b, nb, i), s2, e2);
+            if (e2 - s2 == e1 - s1 && std::memcmp(a + s1, b + s2, e1 - s1) == 0) { at2 = i; return true; }
+            for (int l = 0; l < 4; l++) i = next_line(b, nb, i);
+        }
+        return false;
+    }
 
     void run_image(const uint8_t *map, size_t nb, const char *result)
     {
-        struct timeval t0, t1;
+        struct timeval t0;
         gettimeofday(&t0, nullptr);
         // Large files are STREAMED: cut into byte ranges at record starts, one per batch, and each range is
         // indexed, packed and submitted by one task -- no index of the whole file first, nothing waits for the
@@ -252,16 +312,11 @@ struct Classifier {
         bool done = false;
         if (nb >= stream_min && !opt.dump && (map[0] == '>' || map[0] == '@')) done = classify_image(map, nb, result, true);
         if (!done) classify_image(map, nb, result, false);
-        gettimeofday(&t1, nullptr);
-        const double diff = (t1.tv_sec - t0.tv_sec) + (t1.tv_usec - t0.tv_usec) / 1000000.0;
-        char buf[256];
-        std::snprintf(buf, sizeof buf, "Done in %.1fs (%zu reads/min, %zu reads)\n", diff,
-                      (size_t)(((double)n_objects) / diff * 60.0), n_objects);
-        std::cerr << buf << "Results: " << result << ".csv\n";
+        done_line(t0, result);
     }
 
     // false: the streamed attempt met a byte range its buffers do not take (nothing of the result is kept)
-    bool classify_image(const uint8_t *map, size_t nb, const char *result, const bool streamed)
+    bool classify_image(const uint8_t *map, size_t nb, const char *result, const bool streamed, const Mates *mates = nullptr)
     {
         const std::string csv = std::string(result) + ".csv";
         FILE *fout = std::fopen(csv.c_str(), "w");
@@ -288,7 +343,7 @@ struct Classifier {
                 const double per_read = (double)H.spos[hn] / (double)hn;         // bytes per record
                 const double con_per_read = (double)container_bound(H, 0, hn, (unsigned)opt.k) / (double)hn;
                 guess_reads = (size_t)((double)nb / per_read / (double)nbatch_g * 1.10) + 64;
-                guess_con = (size_t)((double)guess_reads * con_per_read * 1.05) + 64;
+                guess_con = (size_t)((double)guess_reads * con_per_read * (mates ? 2.2 : 1.05)) + 64;      // (a mate of its own per read)
                 guess_nbuf = std::min(nbatch_g, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
                 if (guess_con <= 0xFFFFFFFFull)
                     early_alloc = std::thread([&]() {
@@ -301,7 +356,7 @@ struct Classifier {
 
         size_t nbatch, nbuf, cap_reads = 0, cap_con = 0;
         std::vector<Batch> B;
-        std::vector<size_t> cut;                      // streamed: byte range of batch b = [cut[b], cut[b + 1])
+        std::vector<size_t> cut, cut2;                // streamed: byte range of batch b = [cut[b], cut[b + 1]) (cut2: of file 2)
         double ts1, ts2;
         if (streamed) {
             nbatch = nbatch_g;
@@ -311,6 +366,24 @@ struct Classifier {
             cut.resize(nbatch + 1);
             for (size_t b = 0; b <= nbatch; b++)
                 cut[b] = b == nbatch ? nb : record_start_at_or_after(map, nb, (size_t)((unsigned __int128)nb * b / nbatch), fastq);
+            if (mates) {
+                // the same cuts in file 2, by id
+                cut2.resize(nbatch + 1);
+                bool found = true;
+                for (size_t b = 0; b <= nbatch && found; b++) {
+                    if (b == 0) cut2[b] = 0;
+                    else if (cut[b] >= nb) cut2[b] = mates->nb;
+                    else found = find_mate(map, nb, cut[b], mates->b, mates->nb, cut2[b]);
+                }
+                for (size_t b = 0; b < nbatch && found; b++) found = cut2[b] <= cut2[b + 1];
+                if (!found) {          // not the regular pair of files this plan is for: join the mates first
+                    if (opt.verbose) std::cerr << "streamed ingest of the two files given up (a record of file 1 has no mate at its place in file 2); joining the mates first\n";
+                    early_alloc.join();
+                    if (early_rc == MC_OK) mc_group_free_batches(grp);
+                    std::fclose(fout);
+                    return false;
+                }
+            }
             B.resize(nbatch);
             ts1 = ts2 = now();
         } else {
@@ -371,7 +444,23 @@ struct Classifier {
             X.R = &X.own; X.text = map + cut[b]; X.r0 = 0;
             if (len && !index_reads(map + cut[b], len, X.own, ierr)) { std::cerr << ierr << std::endl; std::exit(-1); }
             X.n = X.own.size();
-            const bool fits = X.n <= cap_reads && container_bound(X.own, 0, X.n, (unsigned)opt.k) <= cap_con;
+            bool mates_ok = true;
+            if (mates) {
+                // the same records of file 2; names become the ids, lengths the joined lengths (R1 'N' R2)
+                const size_t len2 = cut2[b + 1] - cut2[b];
+                X.text2 = mates->b + cut2[b];
+                if (len2 && !index_reads(mates->b + cut2[b], len2, X.own2, ierr)) mates_ok = false;
+                mates_ok = mates_ok && X.own2.size() == X.n;
+                for (size_t i = 0; mates_ok && i < X.n; i++) {
+                    size_t s1, e1, s2, e2;
+                    mate_id(X.text, X.own.name_s[i] - 1, line_end(X.text, len, X.own.name_s[i] - 1), s1, e1);
+                    mate_id(X.text2, X.own2.name_s[i] - 1, line_end(X.text2, len2, X.own2.name_s[i] - 1), s2, e2);
+                    mates_ok = e1 - s1 == e2 - s2 && std::memcmp(X.text + s1, X.text2 + s2, e1 - s1) == 0;
+                    X.own.name_s[i] = s1; X.own.name_e[i] = e1;
+                    X.own.len[i] = X.own.len[i] + 1 + X.own2.len[i];
+                }
+            }
+            const bool fits = mates_ok && X.n <= cap_reads && container_bound(X.own, 0, X.n, (unsigned)opt.k) <= cap_con;
             { std::lock_guard<std::mutex> lk(done_mu); X.indexed = true; if (!fits) gave_up = true; }
             done_cv.notify_all();
         };
@@ -387,7 +476,9 @@ struct Classifier {
                 const uint32_t buf = (uint32_t)(b % nbuf);
                 uint32_t *ptr; uint16_t *con;
                 mc_check(mc_group_batch_buffers(grp, buf, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
-                X.ncon = pack_reads(X.text, *X.R, X.r0, X.r0 + X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text));
+                X.ncon = mates ? pack_mates(X.text, X.own, X.text2, X.own2, X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text),
+                                            (size_t)(mates->b + mates->nb - X.text2))
+                               : pack_reads(X.text, *X.R, X.r0, X.r0 + X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text));
                 std::lock_guard<std::mutex> lk(submit_mu);
                 mc_check(mc_group_submit(grp, buf, X.n, X.ncon, flags), "mc_group_submit");
             }
@@ -589,7 +680,7 @@ struct Classifier {
                     str.drop();
                 });
             }
-            if (streamed) B[b].own = ReadIndex();              // this range's index is not needed any more
+            if (streamed) { B[b].own = ReadIndex(); B[b].own2 = ReadIndex(); }      // this range's index is not needed any more
         }
         pool.finish();
         if (!ok) {
@@ -597,7 +688,8 @@ struct Classifier {
             mc_group_sync(grp);
             mc_group_free_batches(grp);
             std::fclose(fout);
-            if (opt.verbose) std::cerr << "streamed ingest given up (a range of the file exceeds the guessed buffers); indexing the whole file\n";
+            if (opt.verbose) std::cerr << (mates ? "streamed ingest of the two files given up (mates out of step, or a range exceeds the guessed buffers); joining the mates first\n"
+                                                 : "streamed ingest given up (a range of the file exceeds the guessed buffers); indexing the whole file\n");
             return false;
         }
         n_objects = n_done;
@@ -615,7 +707,7 @@ struct Classifier {
         std::fclose(fout);
         if (opt.verbose) {
             if (streamed)
-                std::cerr << "timing: streamed (" << nbatch << " byte ranges: index | pack+submit | wait+format+write, all overlapped) "
+                std::cerr << "timing: streamed (" << nbatch << (mates ? " byte ranges of both files" : " byte ranges") << ": index | pack+submit | wait+format+write, all overlapped) "
                           << now() - ts0 << " s\n";
             else
                 std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "

@@ -311,50 +311,73 @@ inline size_t container_bound(const ReadIndex &R, size_t r0, size_t r1, unsigned
     return c + 8;
 }
 
+// The parts of the bytes [i, e) of t -- maximal runs of bases at least k long -- appended to con[] at `count`; returns
+// the new count.  `avail`: bytes that may be read from t (0 = unknown: no loads past e).
+inline size_t pack_segment(const uint8_t *t, size_t i, const size_t e, unsigned k, uint16_t *con, size_t count, size_t avail)
+{
+    const auto &ct = codes();
+    while (i < e) {
+        // skip to the start of a run
+        while (i < e && ct.r[t[i]] < 0) i++;
+        if (i >= e) break;
+        const size_t slot = count++;      // length slot of this part
+        uint32_t plen = 0, cur = 0;
+        uint16_t w = 0;
+        {   // whole 32-base blocks of the run, vectorised; the scalar loop takes over at the first other byte
+            const size_t done = pack_blocks(t + i, e - i, con + count);
+            i += done; count += done / 8; plen += (uint32_t)done;
+            // what is left of a run that ends with the sequence (fewer than 32 bases): one masked block
+            const size_t rem = e - i;
+            if (rem && rem < 32 && i + 32 <= avail && pack_tail(t + i, rem, con + count)) {
+                i = e; count += (rem + 7) / 8; plen += (uint32_t)rem;
+            }
+        }
+        while (i < e) {
+            const int code = ct.r[t[i]];
+            if (code < 0) {
+                if (t[i] == '\n') { i++; continue; }
+                break;
+            }
+            w = (uint16_t)((w << 2) | code);
+            i++;
+            if (++cur == 8) { con[count++] = w; plen += 8; cur = 0; w = 0; }
+        }
+        if (cur) { con[count++] = (uint16_t)(w << (2 * (8 - cur))); plen += cur; }
+        if (plen < k) count = slot;           // too short: drop the part
+        else con[slot] = (uint16_t)plen;      // a part is at most 65535 bases (u16 slot)
+    }
+    return count;
+}
+
 // Pack reads [r0, r1) of the file image.  Returns the number of containers written.
 // `avail`: bytes that may be read from t (the rest of the file image; 0 = unknown: no loads past a read's end).
 inline size_t pack_reads(const uint8_t *t, const ReadIndex &R, size_t r0, size_t r1, unsigned k,
                          uint32_t *ptr, uint16_t *con, size_t avail = 0)
 {
-    const auto &ct = codes();
     size_t count = 0;
     for (size_t ir = r0; ir < r1; ir++) {
         ptr[ir - r0] = (uint32_t)count;
         if (R.len[ir] < k) continue;
-        size_t i = R.spos[ir];
-        const size_t e = R.epos[ir];
-        while (i < e) {
-            // skip to the start of a run
-            while (i < e && ct.r[t[i]] < 0) i++;
-            if (i >= e) break;
-            const size_t slot = count++;      // length slot of this part
-            uint32_t plen = 0, cur = 0;
-            uint16_t w = 0;
-            {   // whole 32-base blocks of the run, vectorised; the scalar loop takes over at the first other byte
-                const size_t done = pack_blocks(t + i, e - i, con + count);
-                i += done; count += done / 8; plen += (uint32_t)done;
-                // what is left of a run that ends with the sequence (fewer than 32 bases): one masked block
-                const size_t rem = e - i;
-                if (rem && rem < 32 && i + 32 <= avail && pack_tail(t + i, rem, con + count)) {
-                    i = e; count += (rem + 7) / 8; plen += (uint32_t)rem;
-                }
-            }
-            while (i < e) {
-                const int code = ct.r[t[i]];
-                if (code < 0) {
-                    if (t[i] == '\n') { i++; continue; }
-                    break;
-                }
-                w = (uint16_t)((w << 2) | code);
-                i++;
-                if (++cur == 8) { con[count++] = w; plen += 8; cur = 0; w = 0; }
-            }
-            if (cur) { con[count++] = (uint16_t)(w << (2 * (8 - cur))); plen += cur; }
-            if (plen < k) count = slot;           // too short: drop the part
-            else con[slot] = (uint16_t)plen;      // a part is at most 65535 bases (u16 slot)
-        }
+        count = pack_segment(t, R.spos[ir], R.epos[ir], k, con, count, avail);
     }
     ptr[r1 - r0] = (uint32_t)count;
+    return count;
+}
+
+// Paired mates straight from their two files: read i = the sequence of record i of file 1, an 'N', the sequence of
+// record i of file 2 (what the joined record ">id\nR1NR2" of src/file.cc:205-268 packs to: the N ends a part).
+// R1.len holds the joined length (len1 + 1 + len2).
+inline size_t pack_mates(const uint8_t *t1, const ReadIndex &R1, const uint8_t *t2, const ReadIndex &R2, size_t n, unsigned k,
+                         uint32_t *ptr, uint16_t *con, size_t avail1, size_t avail2)
+{
+    size_t count = 0;
+    for (size_t ir = 0; ir < n; ir++) {
+        ptr[ir] = (uint32_t)count;
+        if (R1.len[ir] < k) continue;
+        count = pack_segment(t1, R1.spos[ir], R1.epos[ir], k, con, count, avail1);
+        count = pack_segment(t2, R2.spos[ir], R2.epos[ir], k, con, count, avail2);
+    }
+    ptr[n] = (uint32_t)count;
     return count;
 }
 

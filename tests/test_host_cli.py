@@ -265,14 +265,17 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fastq", "fasta_70", "paired", "extended", "gives_up"])
+@pytest.mark.parametrize("mode", ["fastq", "fasta_70", "paired", "paired_extra_mate", "paired_changed_id", "extended", "gives_up"])
 def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     """Large files are cut into byte ranges at record starts and every range is indexed, packed and submitted by
     one task (host/main.cc classify_image, streamed plan; MC_STREAM_MIN_BYTES lowers the size it starts at).  The
     CSV must not depend on it: FASTQ, multi-line FASTA, joined mates and the extended table against the oracle
     with 9 ranges on 4 threads; `gives_up`: long reads first, then ten times as many short ones -- the ranges at
     the end hold more reads than the buffers guessed from the head take, and the run starts over with the plan
-    that indexes the whole file first"""
+    that indexes the whole file first.  `paired`: the mates are classified straight from their two files (byte ranges
+    of file 1, the matching records of file 2 found by id: no joined text); `paired_extra_mate`: file 2 holds one
+    record more -- the ranges do not pair up and the mates are joined first, as for small files;
+    `paired_changed_id`: the reference's message and exit status"""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import mixed_fasta
@@ -285,14 +288,19 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     dbdir.mkdir()
     names, seqs = mixed_fasta(genomes, k, seed=17, n=3000)
     args = ["-T", targets, "-D", str(dbdir), "-R", str(tmp_path / "res"), "-n", "4", "-b", "9", "--verbose"]
-    paired = mode == "paired"
+    paired = mode.startswith("paired")
     if paired:
         m1 = [s[:100].replace(b"\n", b"") for s in seqs]
         m2 = [s[50:150] for s in seqs]
         nm = [n.split(b" ")[0] for n in names]
         f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
         f1.write_bytes(synth.fastq_text([n + b"/1" for n in nm], m1))
-        f2.write_bytes(synth.fastq_text([n + b"/2" for n in nm], m2))
+        t2 = synth.fastq_text([n + b"/2" for n in nm], m2)
+        if mode == "paired_extra_mate":
+            t2 += b"@lonely/2\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"
+        if mode == "paired_changed_id":
+            t2 = t2.replace(nm[2000] + b"/2", nm[2000] + b"x/2", 1)
+        f2.write_bytes(t2)
         args += ["-P", str(f1), str(f2)]
         text = synth.fasta_text(nm, [a + b"N" + b for a, b in zip(m1, m2)])
     elif mode == "fasta_70":
@@ -312,9 +320,14 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
         p.write_bytes(text)
         args += ["-O", str(p)] + (["--extended"] if mode == "extended" else [])
     r = _run("cuCLARK-l", args, env={"MC_STREAM_MIN_BYTES": "1"})
+    if mode == "paired_changed_id":
+        assert r.returncode != 0 and "Error: read id does not match between files!" in r.stderr, r.stderr
+        return
     assert r.returncode == 0, r.stderr
     assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up"), r.stderr
+    assert ("streamed ingest of the two files given up" in r.stderr) == (mode == "paired_extra_mate"), r.stderr
     assert ("timing: streamed" in r.stderr) == (mode != "gives_up"), r.stderr
+    assert ("byte ranges of both files" in r.stderr) == (mode == "paired"), r.stderr
     base = str(dbdir / ("db_central_k27_t4_s%d_m0_light_4.tsk" % ht))
     want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, paired=paired, extended=mode == "extended")
     assert open(str(tmp_path / "res.csv")).read() == want
