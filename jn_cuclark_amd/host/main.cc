@@ -286,7 +286,8 @@ struct Classifier {
         size_t s1, e1;
         mate_id(a, at1, line_end(a, na, at1), s1, e1);
         const size_t guess = (size_t)((unsigned __int128)nb * at1 / (na ? na : 1));
-        const size_t window = 256u << 10;
+        size_t window = 256u << 10;
+        if (const char *e = getenv("MC_MATE_WINDOW")) window = (size_t)std::strtoull(e, nullptr, 10);      // (tests)
         size_t i = record_start_at_or_after(b, nb, guess > window ? guess - window : 0, true);
         const size_t stop = std::min(nb, guess + window);
         while (i < stop) {
@@ -376,6 +377,11 @@ struct Classifier {
                     else found = find_mate(map, nb, cut[b], mates->b, mates->nb, cut2[b]);
                 }
                 for (size_t b = 0; b < nbatch && found; b++) found = cut2[b] <= cut2[b + 1];
+                if (!found) {
+                    // mates that are not at the same relative place (reads trimmed to different lengths): count records
+                    found = align_mates(map, nb, mates->b, mates->nb, cut, (int)opt.cpu, cut2);
+                    if (found && opt.verbose) std::cerr << "mates located by counting records (not at the same relative place of the two files)\n";
+                }
                 if (!found) {          // not the regular pair of files this plan is for: join the mates first
                     if (opt.verbose) std::cerr << "streamed ingest of the two files given up (a record of file 1 has no mate at its place in file 2); joining the mates first\n";
                     early_alloc.join();

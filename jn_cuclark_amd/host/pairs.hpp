@@ -56,6 +56,43 @@ inline size_t skip_records(const uint8_t *t, size_t nb, size_t from, size_t skip
 
 } // namespace pairs_detail
 
+// Where the records that start at cutA[i] in file 1 have their mates in file 2, by counting: the records of every range
+// of file 1 and of as many byte ranges of file 2 are counted on `n_threads` threads, and the mate of the first record of
+// range i is the record with the same number.  false: the files are not regular (a record that is not four lines, or
+// different record counts).  cutA: ascending record starts, cutA.front() = 0, cutA.back() = na.
+inline bool align_mates(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, const std::vector<size_t> &cutA,
+                        int n_threads, std::vector<size_t> &cutB)
+{
+    using namespace pairs_detail;
+    const int P = (int)cutA.size() - 1;
+    if (P < 1) return false;
+    std::vector<Range> RA(P), RB(P);
+    for (int i = 0; i < P; i++) {
+        RA[i].begin = cutA[i]; RA[i].end = cutA[i + 1];
+        RB[i].begin = record_start_at_or_after(b, nb, nb / P * i, true);
+    }
+    for (int i = 0; i < P; i++) RB[i].end = i + 1 < P ? RB[i + 1].begin : nb;
+    for_each_index(2 * P, n_threads, [&](int i) {
+        if (i < P) count_records(a, na, RA[i]); else count_records(b, nb, RB[i - P]);
+    });
+    std::vector<size_t> firstA(P + 1, 0), firstB(P + 1, 0);
+    bool regular = true;
+    for (int i = 0; i < P; i++) {
+        regular = regular && RA[i].regular && RB[i].regular;
+        firstA[i + 1] = firstA[i] + RA[i].records;
+        firstB[i + 1] = firstB[i] + RB[i].records;
+    }
+    if (!regular || firstA[P] != firstB[P]) return false;
+    cutB.assign(P + 1, nb);
+    for_each_index(P, n_threads, [&](int i) {
+        int j = 0;
+        while (j + 1 < P && firstB[j + 1] <= firstA[i]) j++;
+        cutB[i] = skip_records(b, nb, RB[j].begin, firstA[i] - firstB[j]);
+    });
+    cutB[P] = nb;
+    return true;
+}
+
 inline bool merge_paired_parallel(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, int n_threads,
                                   uint8_t **out, size_t *out_len, std::string &err)
 {

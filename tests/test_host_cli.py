@@ -218,6 +218,8 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
     if paired:
         m1 = [s[:100].replace(b"\n", b"") for s in seqs]
         m2 = [s[50:150] for s in seqs]
+        if mode == "paired_drift":
+            m2 = [s[50:90] if i < len(seqs) // 2 else s[20:150] for i, s in enumerate(seqs)]
         nm = [n.split(b" ")[0] for n in names]
         f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
         t1, t2 = synth.fastq_text([n + b"/1" for n in nm], m1), synth.fastq_text([n + b"/2" for n in nm], m2)
@@ -265,7 +267,7 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fastq", "fasta_70", "paired", "paired_extra_mate", "paired_changed_id", "extended", "gives_up"])
+@pytest.mark.parametrize("mode", ["fastq", "fasta_70", "paired", "paired_drift", "paired_extra_mate", "paired_changed_id", "extended", "gives_up"])
 def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     """Large files are cut into byte ranges at record starts and every range is indexed, packed and submitted by
     one task (host/main.cc classify_image, streamed plan; MC_STREAM_MIN_BYTES lowers the size it starts at).  The
@@ -275,7 +277,9 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     that indexes the whole file first.  `paired`: the mates are classified straight from their two files (byte ranges
     of file 1, the matching records of file 2 found by id: no joined text); `paired_extra_mate`: file 2 holds one
     record more -- the ranges do not pair up and the mates are joined first, as for small files;
-    `paired_changed_id`: the reference's message and exit status"""
+    `paired_changed_id`: the reference's message and exit status; `paired_drift`: the mates of the first half are short,
+    those of the second long, so a record's mate is NOT at the same relative place of file 2 (search window cut to 2 KB
+    for the test) and the ranges are paired up by counting records instead"""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import mixed_fasta
@@ -319,7 +323,7 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
         p = tmp_path / "reads.fq"
         p.write_bytes(text)
         args += ["-O", str(p)] + (["--extended"] if mode == "extended" else [])
-    r = _run("cuCLARK-l", args, env={"MC_STREAM_MIN_BYTES": "1"})
+    r = _run("cuCLARK-l", args, env={"MC_STREAM_MIN_BYTES": "1", "MC_MATE_WINDOW": "2048" if mode == "paired_drift" else "262144"})
     if mode == "paired_changed_id":
         assert r.returncode != 0 and "Error: read id does not match between files!" in r.stderr, r.stderr
         return
@@ -327,7 +331,8 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up"), r.stderr
     assert ("streamed ingest of the two files given up" in r.stderr) == (mode == "paired_extra_mate"), r.stderr
     assert ("timing: streamed" in r.stderr) == (mode != "gives_up"), r.stderr
-    assert ("byte ranges of both files" in r.stderr) == (mode == "paired"), r.stderr
+    assert ("byte ranges of both files" in r.stderr) == (mode in ("paired", "paired_drift")), r.stderr
+    assert ("mates located by counting records" in r.stderr) == (mode == "paired_drift"), r.stderr
     base = str(dbdir / ("db_central_k27_t4_s%d_m0_light_4.tsk" % ht))
     want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, paired=paired, extended=mode == "extended")
     assert open(str(tmp_path / "res.csv")).read() == want
