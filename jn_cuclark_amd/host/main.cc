@@ -293,7 +293,10 @@ struct Classifier {
         while (i < stop) {
             size_t s2, e2;
             mate_id(b, i, line_end(b, nb, i), s2, e2);
-            if (e2 - s2 == e1 - s1 && std::memcmp(a + s1, b + s2, e1 - s1) == 0) { at2 = i; return true; }
+            if (e2 - s2 == e1 - s1 && std::memcmp(a + s1, b + s2, e1 - s1) == 0) {
+                if (getenv("MC_DEBUG_MATES")) std::cerr << "find_mate: at1 " << at1 << " guess " << guess << " window " << window << " found at " << i << "\n";
+                at2 = i; return true;
+            }
             for (int l = 0; l < 4; l++) i = next_line(b, nb, i);
         }
         return false;

@@ -218,8 +218,6 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
     if paired:
         m1 = [s[:100].replace(b"\n", b"") for s in seqs]
         m2 = [s[50:150] for s in seqs]
-        if mode == "paired_drift":
-            m2 = [s[50:90] if i < len(seqs) // 2 else s[20:150] for i, s in enumerate(seqs)]
         nm = [n.split(b" ")[0] for n in names]
         f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
         t1, t2 = synth.fastq_text([n + b"/1" for n in nm], m1), synth.fastq_text([n + b"/2" for n in nm], m2)
@@ -296,6 +294,8 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     if paired:
         m1 = [s[:100].replace(b"\n", b"") for s in seqs]
         m2 = [s[50:150] for s in seqs]
+        if mode == "paired_drift":
+            m2 = [s[50:90] if i < len(seqs) // 2 else s[20:150] for i, s in enumerate(seqs)]
         nm = [n.split(b" ")[0] for n in names]
         f1, f2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
         f1.write_bytes(synth.fastq_text([n + b"/1" for n in nm], m1))
