@@ -55,7 +55,7 @@ def test_mixed_reads_bit_exact(gpu, oracle, fmt, index_mode):
     assert (want[:, 2] > 0).sum() > 1000
 
 
-@pytest.mark.parametrize("length", [21, 22, 84, 85, 86, 139, 140, 141, 148, 149, 150, 151, 277, 501, 1000])
+@pytest.mark.parametrize("length", [21, 22, 84, 85, 86, 139, 140, 141, 142, 143, 144, 145, 148, 149, 150, 151, 269, 272, 277, 501, 1000])
 def test_read_lengths_around_wave_boundaries(gpu, oracle, length):
     """k-mers per read around 64 / 128 (one / two wave steps) and long reads"""
     genomes, sz, ky, lb = small_db(glen=6000)
