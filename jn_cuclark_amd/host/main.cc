@@ -13,6 +13,10 @@
 // exchange of the per-read rows when it does not -- the reference always shards (:552-559).
 // --tsk: the per-target .ht text files are written with the database (host/dbbuild.hpp); the reference's
 // recovery path that rebuilds a vanished database from them (src/CuCLARK_hh.hh:633-684) is not.
+// Ingest (classify_image): files of 8 MiB and more are cut into -b byte ranges at record starts and every range is
+// indexed, packed and submitted by one task of a thread pool that also formats and writes the CSV slices; large
+// regular mate pairs (-P) go the same way straight from their two files; small, irregular or --dump-batches
+// inputs are indexed (and mates joined) as a whole first.  The CSV does not depend on the plan.
 #include "../../include/mc_api.h"
 #include "../../include/mc_group.h"
 #include "common.hpp"
