@@ -1,6 +1,8 @@
 // Test harness for jn_cuclark_amd/host/input.hpp (no GPU needed):
 //   host_input load <file>        -> the input image (gzip inflated) on stdout
 //   host_input pair <f1> <f2>     -> the joined mates on stdout
+//   host_input pairp <f1> <f2> <threads> -> the same join on several threads (pairs.hpp)
+//   host_input packm <f1> <f2> <k>   -> the mates packed straight from the two files (pack_mates), same output format as pack
 //   host_input pack <file> <k> <threads>  -> index + 2-bit pack of the whole file as ONE batch, on stdout:
 //                                    u64 n_reads, u64 n_containers, u32 reads_ptr[n+1], u16 containers[]
 // exit code 2 + message on stderr on failure.
@@ -19,6 +21,22 @@ int main(int argc, char **argv)
         host::InputImage img;
         if (!img.load(argv[2], err)) { std::cerr << err << std::endl; return 2; }
         std::fwrite(img.data(), 1, img.size(), stdout);
+        return 0;
+    }
+    if (argc == 5 && std::string(argv[1]) == "packm") {       // mates packed straight from their two files (reads.hpp pack_mates)
+        host::InputImage a, b;
+        if (!a.load(argv[2], err) || !b.load(argv[3], err)) { std::cerr << err << std::endl; return 2; }
+        const unsigned k = (unsigned)atoi(argv[4]);
+        host::ReadIndex R1, R2;
+        if (!host::index_reads(a.data(), a.size(), R1, err) || !host::index_reads(b.data(), b.size(), R2, err)) { std::cerr << err << std::endl; return 2; }
+        if (R1.size() != R2.size()) { std::cerr << "record counts differ" << std::endl; return 2; }
+        const uint64_t n = R1.size();
+        for (uint64_t i = 0; i < n; i++) R1.len[i] = R1.len[i] + 1 + R2.len[i];          // joined length: R1 'N' R2
+        std::vector<uint32_t> ptr(n + 1);
+        std::vector<uint16_t> con(host::container_bound(R1, 0, n, k));
+        const uint64_t c = host::pack_mates(a.data(), R1, b.data(), R2, n, k, ptr.data(), con.data(), a.size(), b.size());
+        std::fwrite(&n, 8, 1, stdout); std::fwrite(&c, 8, 1, stdout);
+        std::fwrite(ptr.data(), 4, n + 1, stdout); std::fwrite(con.data(), 2, c, stdout);
         return 0;
     }
     if (argc == 5 && std::string(argv[1]) == "pairp") {       // the join on argv[4] threads (pairs.hpp)

@@ -101,6 +101,37 @@ def test_database_build_from_targets_matches_model(oracle, tmp_path, variant):
         assert r.returncode != 0 and "No HIP devices" in r.stderr      # no silent CPU fallback
 
 
+def test_mates_packed_from_two_files_equal_the_joined_records(tmp_path):
+    """host/reads.hpp pack_mates (what the streamed plan of -P uses: no joined text) against the packer run on the
+    joined records ">id\\nR1NR2" of the sequential join: mates with N, lower case, U, mates shorter than k, empty
+    mates, lengths around the 32-base blocks of the vectorised packer -- same offsets, same containers"""
+    exe = _input_harness(tmp_path)
+    rng = np.random.default_rng(11)
+    k, n = 27, 4000
+    alpha = np.frombuffer(b"ACGTacgtUNn-", dtype=np.uint8)
+    weights = np.array([20, 20, 20, 20, 2, 2, 2, 2, 1, 1, 1, 1], dtype=np.float64)
+    weights /= weights.sum()
+
+    def mate(i):
+        L = int(rng.choice([0, 5, 26, 27, 28, 31, 32, 33, 63, 64, 65, 100, 150, 151, 250]))
+        return alpha[rng.choice(alpha.size, size=L, p=weights)].tobytes()
+
+    m1, m2 = [mate(i) for i in range(n)], [mate(i) for i in range(n)]
+    f1, f2 = tmp_path / "m_1.fq", tmp_path / "m_2.fq"
+    f1.write_bytes(b"".join(b"@p%d/1\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(m1)))
+    f2.write_bytes(b"".join(b"@p%d/2\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(m2)))
+    joined = subprocess.run([exe, "pair", str(f1), str(f2)], capture_output=True, timeout=300)
+    assert joined.returncode == 0, joined.stderr
+    fj = tmp_path / "joined.fa"
+    fj.write_bytes(joined.stdout)
+    want = subprocess.run([exe, "pack", str(fj), str(k), "1"], capture_output=True, timeout=300)
+    got = subprocess.run([exe, "packm", str(f1), str(f2), str(k)], capture_output=True, timeout=300)
+    assert want.returncode == 0 and got.returncode == 0, (want.stderr, got.stderr)
+    assert got.stdout == want.stdout
+    nn, cc = np.frombuffer(got.stdout, dtype=np.uint64, count=2)
+    assert int(nn) == n and int(cc) > 10 * n
+
+
 def test_parallel_mate_join_equals_the_sequential_one(tmp_path):
     """host/pairs.hpp: paired FASTQ files joined on several threads (byte ranges of file 1 at record starts, the
     matching record of file 2 found from record counts) against the sequential join that restates mergePairedFiles
