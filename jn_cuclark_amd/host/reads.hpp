@@ -221,10 +221,79 @@ inline void index_fastq_avx2(const uint8_t *t, size_t nb, ReadIndex &R)
 }
 #endif
 
+#ifdef MC_HOST_X86
+// FASTA in one sweep over the same newline bitmaps (records as index_reads_with: a header line -- the name ends at the
+// first space/tab/newline BEHIND its first byte, so an empty name swallows the next line -- then sequence lines up to
+// the next line that starts with '>'; the length is the bytes of those lines without the newlines between them).
+__attribute__((target("avx2")))
+inline void index_fasta_avx2(const uint8_t *t, size_t nb, ReadIndex &R)
+{
+    {
+        const size_t guess = nb / 160 + 16;
+        R.name_s.reserve(guess); R.name_e.reserve(guess); R.spos.reserve(guess); R.epos.reserve(guess); R.len.reserve(guess);
+    }
+    const __m256i nl = _mm256_set1_epi8(10);
+    bool header = true;           // the record's header line is not complete yet
+    size_t name_s = 1, s = 0, e = 0, lines = 0;
+    bool done = false;            // the last record was closed by the end of the text
+    auto close_record = [&]() {
+        R.spos.push_back(s); R.epos.push_back(e);
+        R.len.push_back(e > s ? e - s - (lines ? lines - 1 : 0) : 0);
+    };
+    // returns false when the text is used up
+    auto at_newline = [&](size_t pos) -> bool {
+        const size_t next = pos + 1;                      // start of the next line
+        if (header) {
+            if (pos <= name_s) return true;               // the name's first byte is never a separator: the header goes on
+            R.name_s.push_back(name_s);
+            R.name_e.push_back(name_end_avx2(t, nb, name_s, pos));
+            header = false;
+            s = next < nb ? next : nb; e = s; lines = 0;
+        } else {
+            lines++;
+            e = pos;
+        }
+        if (next >= nb) { close_record(); done = true; return false; }
+        if (t[next] == '>') {                             // the sequence (possibly empty) ends here
+            close_record();
+            header = true;
+            name_s = next + 1;
+        }
+        return true;
+    };
+    size_t b = 0;
+    bool more = true;
+    for (; b + 64 <= nb && more; b += 64) {
+        const uint32_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(t + b)), nl));
+        const uint32_t m1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(t + b + 32)), nl));
+        uint64_t m = (uint64_t)m0 | ((uint64_t)m1 << 32);
+        while (m && more) {
+            const size_t pos = b + (size_t)__builtin_ctzll(m);
+            m &= m - 1;
+            more = at_newline(pos);
+        }
+    }
+    if (more) for (size_t i = b; i < nb && more; i++) if (t[i] == 10) more = at_newline(i);
+    if (!done) {
+        // the text ends inside a line
+        if (header) {
+            R.name_s.push_back(name_s);
+            R.name_e.push_back(name_end_avx2(t, nb, name_s, nb));
+            s = nb; e = nb; lines = 0;
+        } else {
+            lines++;
+            e = nb;
+        }
+        close_record();
+    }
+}
+#endif
+
 inline bool index_reads(const uint8_t *t, size_t nb, ReadIndex &R, std::string &err)
 {
 #ifdef MC_HOST_X86
     if (cpu_has_avx2() && nb >= 64 && t[0] == '@' && !getenv("MC_HOST_GENERIC_INDEX")) { index_fastq_avx2(t, nb, R); return true; }
+    if (cpu_has_avx2() && nb >= 64 && t[0] == '>' && !getenv("MC_HOST_GENERIC_INDEX")) { index_fasta_avx2(t, nb, R); return true; }
     if (cpu_has_avx2()) return index_reads_with<NewlineScanAvx2>(t, nb, R, err);
 #endif
     return index_reads_with<NewlineScanLibc>(t, nb, R, err);

@@ -123,6 +123,58 @@ int main(int argc, char **argv)
         return 0;
     }
 #endif
-    std::cerr << "usage: host_input load <file> | pair <f1> <f2> | pack <file> <k> <threads> | indexfuzz <cases>" << std::endl;
+#ifdef MC_HOST_X86
+    if (argc == 3 && std::string(argv[1]) == "indexfuzz_fasta") {
+        // the same for the one-sweep FASTA indexer: multi-line records of random line widths, '>' inside sequences,
+        // blank lines, empty names, records cut off anywhere, bytes overwritten by separators
+        if (!host::cpu_has_avx2()) { std::cout << "no avx2" << std::endl; return 0; }
+        std::mt19937_64 rng(9);
+        const long cases = atol(argv[2]);
+        for (long it = 0; it < cases; it++) {
+            std::vector<uint8_t> t;
+            const int mode = (int)(it % 3);
+            const size_t target = 64 + rng() % 700;
+            t.push_back('>');
+            if (mode == 0) {
+                const char al[] = ">\n\n\n \tACGT>N";
+                while (t.size() < target) t.push_back((uint8_t)al[rng() % (sizeof al - 1)]);
+            } else {
+                while (t.size() < target + 200) {
+                    if (t.size() > 1) t.push_back('>');
+                    const size_t nl = rng() % 30;
+                    for (size_t j = 0; j < nl; j++) t.push_back(rng() % 9 == 0 ? ' ' : (uint8_t)('a' + rng() % 26));
+                    t.push_back('\n');
+                    const size_t L = rng() % 200, w = 1 + rng() % 70;
+                    for (size_t j = 0; j < L; j++) {
+                        t.push_back((uint8_t)"ACGTN>"[rng() % (rng() % 40 == 0 ? 6 : 5)]);
+                        if ((j + 1) % w == 0) t.push_back('\n');
+                    }
+                    if (rng() % 4) t.push_back('\n');
+                    if (rng() % 10 == 0) t.push_back('\n');
+                }
+                t.resize(target + rng() % 200);
+                if (mode == 2) for (int j = 0; j < 3; j++) t[1 + rng() % (t.size() - 1)] = (uint8_t)"\n >\t"[rng() % 5];
+            }
+            t.push_back(0); t.pop_back();
+            host::ReadIndex A, B;
+            host::index_reads_with<host::NewlineScanLibc>(t.data(), t.size(), A, err);
+            host::index_fasta_avx2(t.data(), t.size(), B);
+            bool same = A.size() == B.size() && A.name_s.size() == B.name_s.size() && A.name_e.size() == B.name_e.size() &&
+                        A.spos.size() == B.spos.size() && A.epos.size() == B.epos.size() && A.name_s.size() == A.size() &&
+                        A.name_e.size() == A.size() && A.spos.size() == A.size() && A.epos.size() == A.size();
+            for (size_t i = 0; same && i < A.size(); i++)
+                same = A.name_s[i] == B.name_s[i] && A.name_e[i] == B.name_e[i] && A.spos[i] == B.spos[i] &&
+                       A.epos[i] == B.epos[i] && A.len[i] == B.len[i];
+            if (!same) {
+                std::cerr << "indexers differ on case " << it << " (" << t.size() << " bytes)" << std::endl;
+                std::fwrite(t.data(), 1, t.size(), stderr);
+                return 3;
+            }
+        }
+        std::cout << cases << std::endl;
+        return 0;
+    }
+#endif
+    std::cerr << "usage: host_input load <file> | pair <f1> <f2> | pack <file> <k> <threads> | indexfuzz[_fasta] <cases>" << std::endl;
     return 1;
 }

@@ -547,12 +547,16 @@ def test_indexer_and_vectorised_packer_equal_the_oracle(oracle, tmp_path, fmt):
 
 
 def test_one_sweep_fastq_indexer_equals_the_line_by_line_indexer(tmp_path):
-    """host/reads.hpp index_fastq_avx2 (newline bitmaps of 64-byte blocks, one state machine) against the
+    """host/reads.hpp index_fastq_avx2 / index_fasta_avx2 (newline bitmaps of 64-byte blocks, one state machine) against the
     line-by-line indexer it replaces for FASTQ, which the test above pins to the oracle's restatement of
     src/CuCLARK_hh.hh:1476-1533: 60 000 hostile texts (soups of '@', newlines and blanks, truncated records,
     overwritten separators), every index column equal"""
     exe = _input_harness(tmp_path)
     r = subprocess.run([exe, "indexfuzz", "60000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() in ("60000", "no avx2")
+    # the same for FASTA (index_fasta_avx2): multi-line records, '>' inside sequences, blank lines, empty names
+    r = subprocess.run([exe, "indexfuzz_fasta", "60000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip() in ("60000", "no avx2")
 
