@@ -267,44 +267,6 @@ struct Classifier {
     // file 2 of a pair, when the mates are not joined into one text first (streamed plan only)
     struct Mates { const uint8_t *b; size_t nb; };
 
-    // the id of a FASTQ header line as mergePairedFiles cuts it (src/file.cc:230-247: leading ' ', '/', tab, '@' skipped,
-    // then up to the next of them); [line, end) = the line without its newline
-    static void mate_id(const uint8_t *t, size_t line, size_t end, size_t &s, size_t &e)
-    {
-        auto sep = [](uint8_t c) { return c == ' ' || c == '/' || c == '\t' || c == '@'; };
-        size_t i = line;
-        while (i < end && sep(t[i])) i++;
-        size_t j = i;
-        while (j < end && !sep(t[j])) j++;
-        s = i; e = j;
-    }
-    static size_t line_end(const uint8_t *t, size_t nb, size_t from)
-    {
-        const void *p = from < nb ? std::memchr(t + from, '\n', nb - from) : nullptr;
-        return p ? (size_t)((const uint8_t *)p - t) : nb;
-    }
-    // the record of file 2 whose id equals the id of file 1's record at `at1`, looked for around the same relative
-    // position of file 2 (mates come in the same order; equal read lengths put them at the same fraction exactly)
-    static bool find_mate(const uint8_t *a, size_t na, size_t at1, const uint8_t *b, size_t nb, size_t &at2)
-    {
-        size_t s1, e1;
-        mate_id(a, at1, line_end(a, na, at1), s1, e1);
-        const size_t guess = (size_t)((unsigned __int128)nb * at1 / (na ? na : 1));
-        size_t window = 256u << 10;
-        if (const char *e = getenv("MC_MATE_WINDOW")) window = (size_t)std::strtoull(e, nullptr, 10);      // (tests)
-        size_t i = record_start_at_or_after(b, nb, guess > window ? guess - window : 0, true);
-        const size_t stop = std::min(nb, guess + window);
-        while (i < stop) {
-            size_t s2, e2;
-            mate_id(b, i, line_end(b, nb, i), s2, e2);
-            if (e2 - s2 == e1 - s1 && std::memcmp(a + s1, b + s2, e1 - s1) == 0) {
-                if (getenv("MC_DEBUG_MATES")) std::cerr << "find_mate: at1 " << at1 << " guess " << guess << " window " << window << " found at " << i << "\n";
-                at2 = i; return true;
-            }
-            for (int l = 0; l < 4; l++) i = next_line(b, nb, i);
-        }
-        return false;
-    }
 
     void run_image(const uint8_t *map, size_t nb, const char *result)
     {

@@ -39,6 +39,26 @@ int main(int argc, char **argv)
         std::fwrite(ptr.data(), 4, n + 1, stdout); std::fwrite(con.data(), 2, c, stdout);
         return 0;
     }
+    if (argc == 6 && std::string(argv[1]) == "mates") {       // mates <f1> <f2> <ranges> <window>: where the ranges of file 1 pair up in file 2
+        host::InputImage a, b;
+        if (!a.load(argv[2], err) || !b.load(argv[3], err)) { std::cerr << err << std::endl; return 2; }
+        const int P = atoi(argv[4]);
+        setenv("MC_MATE_WINDOW", argv[5], 1);
+        std::vector<size_t> cut(P + 1), by_id(P + 1, 0), by_count;
+        for (int i = 0; i <= P; i++) cut[i] = i == P ? a.size() : host::record_start_at_or_after(a.data(), a.size(), a.size() / P * i, true);
+        bool found = true;
+        for (int i = 1; i < P && found; i++) found = cut[i] >= a.size() ? (by_id[i] = b.size(), true) : host::find_mate(a.data(), a.size(), cut[i], b.data(), b.size(), by_id[i]);
+        by_id[P] = b.size();
+        const bool counted = host::align_mates(a.data(), a.size(), b.data(), b.size(), cut, 3, by_count);
+        std::cout << "by_id " << (found ? 1 : 0);
+        if (found) for (size_t v : by_id) std::cout << " " << v;
+        std::cout << "\nby_count " << (counted ? 1 : 0);
+        if (counted) for (size_t v : by_count) std::cout << " " << v;
+        std::cout << "\ncuts";
+        for (size_t v : cut) std::cout << " " << v;
+        std::cout << std::endl;
+        return 0;
+    }
     if (argc == 5 && std::string(argv[1]) == "pairp") {       // the join on argv[4] threads (pairs.hpp)
         host::InputImage a, b;
         if (!a.load(argv[2], err) || !b.load(argv[3], err)) { std::cerr << err << std::endl; return 2; }

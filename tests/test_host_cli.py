@@ -132,6 +132,52 @@ def test_mates_packed_from_two_files_equal_the_joined_records(tmp_path):
     assert int(nn) == n and int(cc) > 10 * n
 
 
+def test_ranges_of_file_1_are_paired_up_with_file_2(tmp_path):
+    """host/pairs.hpp find_mate (the record with the same id around the same relative place of file 2) and align_mates
+    (by counting records): for cuts of file 1 at record starts both must return the byte offset of the record with the
+    same index in file 2 -- checked against offsets computed here; with mates that drift (short in the first half, long
+    in the second) and a 1 KB search window the id search must give up while the count still pairs them up; with one
+    record more in file 2 the count must refuse"""
+    exe = _input_harness(tmp_path)
+    rng = np.random.default_rng(8)
+    n = 6000
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, 150))]
+
+    def write(path, tag, lens):
+        offs, out = [], bytearray()
+        for i in range(n):
+            offs.append(len(out))
+            L = int(lens[i])
+            out += b"@q%06d/%s x\n" % (i, tag) + seq[i, :L].tobytes() + b"\n+\n" + b"I" * L + b"\n"
+        path.write_bytes(bytes(out))
+        return offs, len(out)
+
+    f1, f2, f3 = tmp_path / "a_1.fq", tmp_path / "a_2.fq", tmp_path / "a_3.fq"
+    o1, n1 = write(f1, b"1", np.full(n, 150))
+    o2, n2 = write(f2, b"2", 60 + rng.integers(0, 80, n))                 # no drift: the id search finds every mate
+    o3, n3 = write(f3, b"2", np.where(np.arange(n) < n // 2, 40, 140))    # drift
+
+    def run(fa, fb, window):
+        r = subprocess.run([exe, "mates", str(fa), str(fb), "7", str(window)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        rows = {l.split()[0]: [int(v) for v in l.split()[1:]] for l in r.stdout.strip().split("\n")}
+        return rows
+
+    rows = run(f1, f2, 262144)
+    idx = [o1.index(c) if c < n1 else n for c in rows["cuts"]]          # record index of every cut of file 1
+    want = [o2[i] if i < n else n2 for i in idx]
+    assert rows["by_id"][0] == 1 and rows["by_id"][1:] == want
+    assert rows["by_count"][0] == 1 and rows["by_count"][1:] == want
+    rows = run(f1, f3, 1024)
+    want3 = [o3[i] if i < n else n3 for i in idx]
+    assert rows["by_id"][0] == 0
+    assert rows["by_count"][0] == 1 and rows["by_count"][1:] == want3
+    f4 = tmp_path / "a_4.fq"
+    f4.write_bytes(f2.read_bytes() + b"@lonely/2\nACGT\n+\nIIII\n")
+    rows = run(f1, f4, 262144)
+    assert rows["by_count"][0] == 0
+
+
 def test_parallel_mate_join_equals_the_sequential_one(tmp_path):
     """host/pairs.hpp: paired FASTQ files joined on several threads (byte ranges of file 1 at record starts, the
     matching record of file 2 found from record counts) against the sequential join that restates mergePairedFiles
