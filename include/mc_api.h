@@ -75,8 +75,8 @@ typedef struct mc_db_info {
     uint32_t part, n_parts;   /* line-range part of a table spread over n_parts contexts (0 of 1 = whole)  */
     uint64_t n_keys_owned;    /* k-mers this context answers for (= n_keys unless n_parts > 1)            */
     /* minimizer index only (for it n_overflow_buckets = extra lines, n_overflow_keys = spilled k-mers): */
-    uint64_t n_lines;             /* primary lines of the whole table                  */
-    uint64_t line_begin, line_end;/* primary lines held here                           */
+    uint64_t n_lines;             /* primary lines of the whole table (all parts; every part holds n_lines / n_parts) */
+    uint64_t line_begin, line_end;/* primary lines held here: part * n_lines / n_parts and one part further            */
     uint64_t n_extra_lines;       /* lines chained behind overflowing primary lines    */
     uint64_t n_lines_crowded;     /* primary lines with more k-mers than one chain holds (48): their k-mers
                                      are spread over 2^s chains picked by a hash of the k-mer              */
@@ -131,9 +131,10 @@ int mc_load_db_device(mc_ctx *ctx, const uint8_t *d_sz, const void *d_keys, int 
                       const uint16_t *d_labels, uint64_t n_keys,
                       uint64_t shard_begin, uint64_t shard_end);
 
-/* Line-range part of a table that is spread over n_parts contexts (GPUs): this context keeps the k-mers
- * whose minimizer line falls into range `part` of the line space (mc_minimizer.hpp), streams the WHOLE
- * files through the build kernels and drops the rest.  Replaces the same members as mc_load_db for the
+/* Part of a table that is spread over n_parts contexts (GPUs): this context keeps the k-mers whose MINIMIZER
+ * hashes to `part` (mc_minimizer.hpp part_of; line range `part` of the table's line space), streams the WHOLE
+ * files through the build kernels and drops the rest.  All parts must be loaded with the same n_parts on cards of
+ * the same size (the fill is a function of the table, n_parts and the card's HBM; MC_MZ_FILL fixes it).  Replaces the same members as mc_load_db for the
  * multi-device case (the reference gives device d the bucket range m_partPointer[d..d+1],
  * CuClarkDB.cu:552-559, and every device every read batch, :842-851).  Where the reference's bucket ranges
  * scatter the consecutive k-mers of a read over all devices (every device fetches nearly every line), a
@@ -156,6 +157,23 @@ int mc_index_add_host(mc_ctx *ctx, const uint8_t *sz, const void *keys, int key_
                       const uint16_t *labels, uint64_t n_keys, uint64_t bucket_begin, uint64_t bucket_end);
 int mc_index_next_pass(mc_ctx *ctx);
 int mc_index_end(mc_ctx *ctx);
+
+/* The loader's arithmetic, without a device: how a table of n_keys_total k-mers spread over n_parts contexts with
+ * hbm_bytes of free HBM each would be laid out -- k-mers per line (the sparsest of 4 .. 12 that fits, 16 GB kept in
+ * reserve), primary lines and bytes per part, whether it fits at all, and the smallest part count that holds the
+ * table at no more than MC_GROUP_MAX_FILL k-mers per line (what mc_group_load_db cuts it into; 0 = more than 4096).
+ * replaces: the memory budget of CuClarkDB::read (CuClarkDB.cu:516-559: minParts, m_partPointer).
+ * A context addresses at most 2^32 - 16 primary lines (550 GB); a table spread over several contexts has that many
+ * PER PART (the part is drawn from a second hash of the minimizer key, csrc/mc_minimizer.hpp part_of). */
+#define MC_GROUP_MAX_FILL 10.0
+typedef struct mc_index_plan_t {
+    double   fill;            /* k-mers per 12-slot line                                  */
+    uint64_t lines_per_part;  /* primary lines of one part (0: beyond the line index)     */
+    uint64_t bytes_per_part;  /* estimate: lines + extra lines + build counters           */
+    uint32_t fits;            /* 1: bytes_per_part + reserve <= hbm_bytes                  */
+    uint32_t min_parts;       /* smallest n_parts that fits at fill <= MC_GROUP_MAX_FILL   */
+} mc_index_plan_t;
+int mc_index_plan(uint64_t n_keys_total, uint32_t n_parts, uint64_t hbm_bytes, mc_index_plan_t *out);
 
 int mc_get_db_info(mc_ctx *ctx, mc_db_info *out);
 int mc_get_stats(mc_ctx *ctx, mc_stats *out);

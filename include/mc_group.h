@@ -11,9 +11,12 @@
  *
  *   replicas   the table fits one GPU (288 GB: every table the reference targets, up to ~12e9 k-mers):
  *              every GPU holds all of it, batches are dealt round-robin, no exchange at all;
- *   shards     it does not: GPU g holds line range g of the minimizer index (mc_load_db_part; bucket
- *              ranges as in the reference when that index is not available), every GPU gets every batch,
- *              each produces sparse rows for all reads; rows are exchanged device-to-device as a
+ *   shards     it does not: the table is cut into S parts -- as FEW as the cards' memory dictates, like the
+ *              reference's minParts (CuClarkDB.cu:529-559), because every part repeats the front half of the kernel
+ *              for every read -- and the N GPUs form G = N / S groups that each hold the whole table and take
+ *              every G-th batch (S = 1 is "replicas").  Inside a group GPU p holds part p of the minimizer index
+ *              (mc_load_db_part; bucket ranges as in the reference when that index is not available: then one
+ *              group of N), every GPU of the group gets the batch, each produces sparse rows for all its reads; rows are exchanged device-to-device as a
  *              reduce-scatter by read range (GPU j receives every GPU's rows for read range j:
  *              hipMemcpyPeerAsync over xGMI, all links busy once, nothing funnels into device 0), merged
  *              by one k-way kernel and top-2 on the owner, which copies its range of final rows to the
@@ -46,6 +49,9 @@ typedef struct mc_group_info {
     uint64_t device_bytes_max; /* largest per-device share of the database in HBM                  */
     uint64_t bytes_needed_one; /* estimate used for the choice: HBM a full replica needs           */
     uint64_t bytes_free_min;   /* smallest free HBM among the devices when the choice was made     */
+    uint32_t n_shards;         /* S: parts the table is cut into (1 = replicas)                    */
+    uint32_t n_groups;         /* G: groups of S members that each hold the whole table; batches are dealt round-robin
+                                  over the groups, rows are exchanged inside a group; S * G <= n_members              */
 } mc_group_info;
 
 /* replaces: CuClarkDB::CuClarkDB device discovery + peer access (CuClarkDB.cu:118-215).
@@ -60,7 +66,10 @@ int mc_group_close(mc_group *g);
 /* replaces: CuClarkDB::read for all devices (CuClarkDB.cu:463-770), incl. the memory budget that
  * decides how the table is cut (:516-559).  The files are streamed once per build pass and fed to all
  * devices.  mode: MC_GROUP_AUTO / _REPLICAS / _SHARDS (environment MC_GROUP_MODE=replicas|shards
- * overrides AUTO; MC_GROUP_HBM_BYTES caps the per-device memory the choice assumes). */
+ * overrides AUTO; MC_GROUP_HBM_BYTES caps the per-device memory the choice assumes; MC_GROUP_PARTS=S fixes the
+ * part count of a sharded table).  Capacity: a part addresses 2^32 - 16 lines of its own (csrc/mc_minimizer.hpp
+ * part_of), so N cards hold what their HBM holds: about 12e9 k-mers per 288 GB card at the densest fill.
+ * AUTO that finds its estimate too kind (MC_ENOMEM while loading) cuts the table into more parts and tries again. */
 int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t sampling, int mode);
 int mc_group_get_info(mc_group *g, mc_group_info *out);
 /* the member contexts, for mc_get_db_info / mc_get_stats */

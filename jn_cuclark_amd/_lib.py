@@ -33,6 +33,11 @@ class McDbInfo(C.Structure):
 MC_INDEX_BUCKET_LINES, MC_INDEX_MINIMIZER = 0, 1
 
 
+class McIndexPlan(C.Structure):
+    _fields_ = [("fill", C.c_double), ("lines_per_part", C.c_uint64), ("bytes_per_part", C.c_uint64),
+                ("fits", C.c_uint32), ("min_parts", C.c_uint32)]
+
+
 class McStats(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("reads_over_maxhits", C.c_uint64),
                 ("kernel_launches", C.c_uint64)]
@@ -60,6 +65,7 @@ SYMBOLS = [
     ("mc_index_add_host", _i, [_vp, _vp, _vp, _i, _vp, _u64, _u64, _u64]),
     ("mc_index_next_pass", _i, [_vp]),
     ("mc_index_end", _i, [_vp]),
+    ("mc_index_plan", _i, [_u64, _u32, _u64, C.POINTER(McIndexPlan)]),
     ("mc_get_db_info", _i, [_vp, C.POINTER(McDbInfo)]),
     ("mc_get_stats", _i, [_vp, C.POINTER(McStats)]),
     ("mc_alloc_batches", _i, [_vp, _u32, _u64, _u64, _i]),
@@ -92,6 +98,13 @@ def load_library():
             fn.argtypes = args
         _LIB = lib
     return _LIB
+
+
+def index_plan(n_keys_total, n_parts, hbm_bytes):
+    """mc_index_plan: the loader's arithmetic (fill, lines and bytes per part, smallest part count); no device needed"""
+    p = McIndexPlan()
+    check(load_library().mc_index_plan(int(n_keys_total), int(n_parts), int(hbm_bytes), C.byref(p)))
+    return {f: getattr(p, f) for f, _ in McIndexPlan._fields_}
 
 
 def check(rc):

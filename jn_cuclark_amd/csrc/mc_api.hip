@@ -105,19 +105,23 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     // k-mers per 12-slot line.  Fewer per line = fewer overflowing lines = a faster kernel (genome-shaped table,
     // 5.5e9 k-mers: 4 / 5 / 6 / 8 per line -> 993 / 913 / 828 / 705 Mreads/s at 193 / 161 / 140 / 126 GB), so a table
     // that is alone on the card takes the room it finds: the sparsest fill in [4, 12] that leaves 16 GB free.
-    // Parts of one table must agree on the line space and use the default (the group loader picks for all).
-    double per_line = c->fill_hint > 0.0 ? c->fill_hint : 6.0;
+    // Parts of one table must agree on the fill: a caller that builds the parts one by one (mc_load_db_part,
+    // mc_index_begin with n_parts > 1) gets the fill every part can afford IF each has a card like this one to
+    // itself -- a pure function of (n_keys_total, n_parts, HBM of the card) -- unless a group loader chose
+    // (fill_hint) or MC_MZ_FILL says otherwise.
+    double per_line = c->fill_hint;
     if (const char *e = getenv("MC_MZ_FILL")) { const double v = atof(e); if (v >= 1.0 && v <= 64.0) per_line = v; }
-    else if (c->fill_hint <= 0.0 && n_parts == 1) {
+    if (per_line <= 0.0) {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) per_line = mcint::choose_fill(n_keys_total, 1, fr);
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        per_line = mcint::choose_fill(n_keys_total, n_parts, n_parts == 1 ? (uint64_t)fr : (uint64_t)tot);
     }
-    const uint64_t want = (uint64_t)((double)n_keys_total / per_line) + 1024;
-    if (want >= 0xFFFFFFF0ull) return fail(MC_EINVAL, "minimizer index: too many lines");
-    const uint32_t n_lines = (uint32_t)want;
-    c->mz_n_lines = n_lines;
-    c->mz_line0 = (uint32_t)((uint64_t)n_lines * part / n_parts);
-    c->mz_n_local = (uint32_t)((uint64_t)n_lines * (part + 1) / n_parts) - c->mz_line0;
+    const uint64_t want = mcint::lines_per_part(n_keys_total, n_parts, per_line);
+    if (want == 0)
+        return fail(MC_EINVAL, "minimizer index: " + std::to_string(n_keys_total) + " k-mers at " + std::to_string(per_line) +
+                               " per line over " + std::to_string(n_parts) + " part(s) need more than 2^32 lines per part");
+    c->mz_n_local = (uint32_t)want;
+    c->mz_part = part; c->mz_n_parts = n_parts;
     c->mz_m = mc::mz::mmer_len(c->k);
     c->info = mc_db_info{};
     c->info.part = part; c->info.n_parts = n_parts;
@@ -163,12 +167,12 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
     if (c->build.pass == 0)
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
                            static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
-                           c->mz_n_lines, c->mz_line0, c->mz_n_local, c->build.d_count,
+                           c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
                            (uint8_t *)nullptr, (uint8_t *)nullptr, (unsigned int *)nullptr);
     else
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
                            static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
-                           c->mz_n_lines, c->mz_line0, c->mz_n_local, c->build.d_count,
+                           c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
                            c->d_mz_lines, c->d_mz_extra, c->build.d_failed);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));       // the temporaries go out of scope
@@ -280,7 +284,11 @@ int index_end(mc_ctx *c)
     unsigned int failed = 0;
     HIPCHK(hipMemcpyAsync(&failed, c->build.d_failed, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (failed) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: a chain of a crowded line overflowed twice"); }
+    if (failed) {
+        free_db(c); index_abort(c);
+        return fail(MC_EINVAL, (failed & 2u) ? "minimizer index: the second pass held k-mers the first did not (a line outgrew the chain sized for it)"
+                                             : "minimizer index: a chain of a crowded line overflowed twice");
+    }
     mc_db_info &I = c->info;
     I.htsize = c->htsize;
     I.shard_begin = c->build.bucket_lo == ~0ull ? 0 : c->build.bucket_lo;
@@ -292,7 +300,8 @@ int index_end(mc_ctx *c)
     I.line_capacity = mc::mz::MZ_CAP;
     I.device_bytes = ((uint64_t)c->mz_n_local + c->build.n_extra) * mc::mz::MZ_LINE;
     I.index_kind = MC_INDEX_MINIMIZER;
-    I.n_lines = c->mz_n_lines; I.line_begin = c->mz_line0; I.line_end = c->mz_line0 + c->mz_n_local;
+    I.n_lines = (uint64_t)c->mz_n_local * c->mz_n_parts;                 // part p = lines [p * n, (p + 1) * n) of the table's
+    I.line_begin = (uint64_t)c->mz_n_local * c->mz_part; I.line_end = I.line_begin + c->mz_n_local;
     I.n_extra_lines = c->build.n_extra; I.n_lines_crowded = c->build.n_crowded;
     I.n_lines_overflowing = c->build.n_over; I.n_spilled_keys = c->build.n_spilled; I.largest_line = c->build.longest;
     {   // k-mers this part owns = the sum of its line counters (fed[] counts what streamed past)
@@ -511,7 +520,7 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     if (c->d_mz_lines) {
         mc::mz::MzArgs m{};
         m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra;
-        m.n_lines = c->mz_n_lines; m.line0 = c->mz_line0; m.n_local = c->mz_n_local;
+        m.n_lines = c->mz_n_local; m.part = c->mz_part; m.n_parts = c->mz_n_parts;
         m.m = c->mz_m;
         // canonical k-mers are below 4^k: the floating-point remainder needs k-mer / HTSIZE < 2^32
         const bool fp_ok = c->htsize > 1024 && c->htsize < (1ull << 32) &&
@@ -664,6 +673,15 @@ int DbFileStream::pass(const ChunkFn &f)
     return MC_OK;
 }
 
+// primary lines of one part (every part has the same number); 0 = more than the 32-bit line index of a context holds
+uint64_t lines_per_part(uint64_t n_keys_total, uint32_t n_parts, double fill)
+{
+    if (n_parts < 1 || fill <= 0.0) return 0;
+    const uint64_t total = (uint64_t)((double)n_keys_total / fill) + 1024;
+    const uint64_t per = (total + n_parts - 1) / n_parts;
+    return per >= MZ_MAX_LINES ? 0 : per;
+}
+
 // HBM one context needs for its share of a minimizer index at `fill` k-mers per line: lines, extra lines (the
 // share measured on a genome-shaped table, which overflows more than a random one), build counters
 uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill)
@@ -676,18 +694,27 @@ uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill)
 
 double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes)
 {
-    const uint64_t reserve = 16ull << 30;
+    auto fits = [&](double f) {
+        return lines_per_part(n_keys_total, n_parts, f) != 0 && index_bytes(n_keys_total, n_parts, f) + MZ_RESERVE_BYTES <= free_bytes;
+    };
     for (double f = 4.0; f < 8.0; f += 0.5)
-        if (index_bytes(n_keys_total, n_parts, f) + reserve <= free_bytes) return f;
+        if (fits(f)) return f;
     // past 8 the lines are mostly full and the chains long: slower, but the table stays on the card
     for (double f = 8.0; f < 12.0; f += 1.0)
-        if (index_bytes(n_keys_total, n_parts, f) + reserve <= free_bytes) return f;
+        if (fits(f)) return f;
     return 12.0;
+}
+
+uint32_t min_parts(uint64_t n_keys_total, uint32_t max_parts, uint64_t free_bytes, double max_fill)
+{
+    for (uint32_t s = 1; s <= max_parts; s++)
+        if (lines_per_part(n_keys_total, s, max_fill) != 0 && index_bytes(n_keys_total, s, max_fill) + MZ_RESERVE_BYTES <= free_bytes) return s;
+    return 0;
 }
 
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode == 1 && mz_eligible(c, n_keys_total); }
 
-int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_parts)
+int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts)
 {
     int rc = MC_OK;
     if (!getenv("MC_MZ_FILL")) {
@@ -701,13 +728,13 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_pa
             free_min = std::min<uint64_t>(free_min, fr / sharing);
         }
         if (const char *e = getenv("MC_GROUP_HBM_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) free_min = std::min(free_min, v); }
-        const double f = choose_fill(F.n_keys_kept, line_parts ? n : 1, free_min);
+        const double f = choose_fill(F.n_keys_kept, n_parts, free_min);
         for (uint32_t i = 0; i < n; i++) ctxs[i]->fill_hint = f;
     }
     auto abort_all = [&]() { const std::string keep = g_err; for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); free_db(ctxs[i]); index_abort(ctxs[i]); } g_err = keep; };
     for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
         rc = set_dev(ctxs[i]);
-        if (rc == MC_OK) rc = index_begin(ctxs[i], F.n_keys_kept, line_parts ? i : 0, line_parts ? n : 1);
+        if (rc == MC_OK) rc = index_begin(ctxs[i], F.n_keys_kept, i % n_parts, n_parts);
     }
     for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
         rc = F.pass([&](const uint8_t *sz, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t b0, uint64_t b1) {
@@ -868,7 +895,7 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
     bool fallback = false;
     if (mcint::minimizer_index_possible(c, F.n_keys_kept)) {
         // two passes over the files in chunks: neither the raw arrays nor a second copy ever sits in HBM
-        rc = mcint::load_streamed(&c, 1, F, false);
+        rc = mcint::load_streamed(&c, 1, F, 1);
         if (rc != MC_ENOMEM) return rc;
         fprintf(stderr, "libmcclark: %s; falling back to the bucket-line table\n", g_err.c_str());
         fallback = true;
@@ -958,6 +985,18 @@ int mc_index_end(mc_ctx *c)
     if (!c) return fail(MC_EINVAL, "ctx is NULL");
     int rc = set_dev(c); if (rc) return rc;
     return index_end(c);
+}
+
+int mc_index_plan(uint64_t n_keys_total, uint32_t n_parts, uint64_t hbm_bytes, mc_index_plan_t *out)
+{
+    if (!out || n_parts < 1) return fail(MC_EINVAL, "mc_index_plan: out is NULL or n_parts is 0");
+    const double f = mcint::choose_fill(n_keys_total, n_parts, hbm_bytes);
+    out->fill = f;
+    out->lines_per_part = mcint::lines_per_part(n_keys_total, n_parts, f);
+    out->bytes_per_part = mcint::index_bytes(n_keys_total, n_parts, f);
+    out->fits = out->lines_per_part != 0 && out->bytes_per_part + mcint::MZ_RESERVE_BYTES <= hbm_bytes ? 1u : 0u;
+    out->min_parts = mcint::min_parts(n_keys_total, 4096, hbm_bytes, MC_GROUP_MAX_FILL);
+    return MC_OK;
 }
 
 int mc_get_db_info(mc_ctx *c, mc_db_info *out)

@@ -39,6 +39,7 @@ struct GBatch {
     uint16_t *h_rows = nullptr;
     std::vector<hipEvent_t> done;    // per member
     bool submitted = false;
+    uint32_t first = 0, count = 0;   // the members that worked on the batch as it was last submitted
 };
 
 } // namespace
@@ -58,16 +59,20 @@ struct mc_group {
     // batches may be submitted in any order (the host packs them on several threads): slots and, for
     // replicas, members are dealt by SUBMISSION order
     uint64_t n_submitted = 0;
-    int last_on_slot[2] = {-1, -1};  // shards: the batch whose rows the owners last pulled from this slot
+    // shards: S parts of the table x G groups that each hold all of it.  Member m = part m % S of group m / S;
+    // members past S * G (N not a multiple of S) hold nothing.  A batch goes to ONE group.
+    uint32_t S = 1, G = 1;
+    std::vector<int> last_on_slot;   // [group * 2 + slot]: the batch whose rows the owners last pulled from this slot
 };
 
 namespace {
 
 uint32_t W(const mc_group *g) { return (uint32_t)g->ctx.size(); }
 
+// read range of owner j (part j of the batch's group)
 void range_of(const mc_group *g, uint64_t n_reads, uint32_t j, uint64_t &lo, uint64_t &cnt)
 {
-    const uint64_t per = (n_reads + W(g) - 1) / W(g);
+    const uint64_t per = (n_reads + g->S - 1) / g->S;
     lo = std::min<uint64_t>(n_reads, (uint64_t)j * per);
     cnt = std::min<uint64_t>(n_reads, lo + per) - lo;
 }
@@ -85,7 +90,7 @@ int free_batches(mc_group *g)
             if (b.done[m]) { (void)hipSetDevice(g->ctx[m]->device); (void)hipEventDestroy(b.done[m]); }
     }
     g->batches.clear();
-    g->n_submitted = 0; g->last_on_slot[0] = g->last_on_slot[1] = -1;
+    g->n_submitted = 0; g->last_on_slot.assign((size_t)g->G * 2, -1);
     for (size_t i = 0; i < g->slots.size(); i++) {
         GSlot &s = g->slots[i];
         (void)hipSetDevice(g->ctx[i / 2]->device);
@@ -208,33 +213,65 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
     }
     if (const char *e = getenv("MC_GROUP_HBM_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) free_min = std::min(free_min, v); }
     const uint64_t need_one = bytes_for_table(c0, F.n_keys_kept, g->htsize);
+    const bool want_auto = mode == MC_GROUP_AUTO && !getenv("MC_GROUP_MODE");
     if (mode == MC_GROUP_AUTO) {
         if (const char *e = getenv("MC_GROUP_MODE")) {
             if (!strcmp(e, "replicas")) mode = MC_GROUP_REPLICAS;
             else if (!strcmp(e, "shards")) mode = MC_GROUP_SHARDS;
         }
     }
-    if (mode == MC_GROUP_AUTO) mode = (n == 1 || need_one + (4ull << 30) <= free_min) ? MC_GROUP_REPLICAS : MC_GROUP_SHARDS;
+    const bool by_lines = mz && !(getenv("MC_GROUP_SHARD") && !strcmp(getenv("MC_GROUP_SHARD"), "buckets"));
+    // How many parts.  The reference cuts the table into as few parts as the devices' memory dictates
+    // (minParts, CuClarkDB.cu:529-559) -- every further part repeats the front half of the kernel for every read.
+    // Here: S = the smallest part count whose share fits a device at an acceptable fill, G = N / S groups that
+    // each hold the whole table and take every G-th batch; S = 1 is "replicas".  Bucket-range shards (no
+    // minimizer index) and a forced MC_GROUP_SHARDS keep one group of N parts.
+    uint32_t s_min = 0;
+    if (by_lines) s_min = mcint::min_parts(F.n_keys_kept, n, free_min, MC_GROUP_MAX_FILL);
+    else if (need_one + (4ull << 30) <= free_min) s_min = 1;
+    if (mode == MC_GROUP_AUTO) mode = (n == 1 || s_min == 1) ? MC_GROUP_REPLICAS : MC_GROUP_SHARDS;
     if (n == 1) mode = MC_GROUP_REPLICAS;
+    uint32_t S = 1;
+    if (mode == MC_GROUP_SHARDS) {
+        S = n;
+        if (want_auto && by_lines && s_min >= 2) S = n / (n / s_min);        // G = n / s_min groups, spread evenly
+        if (const char *e = getenv("MC_GROUP_PARTS")) { const long v = atol(e); if (v >= 2 && v <= (long)n && by_lines) S = (uint32_t)v; }
+    }
 
     uint32_t shard_kind = 0;
-    if (mode == MC_GROUP_REPLICAS) {
-        if (mz) rc = mcint::load_streamed(g->ctx.data(), n, F, false);
-        if (!mz || rc == MC_ENOMEM) {
-            for (uint32_t m = 0; m < n; m++) {           // bucket-line tables (or the fallback to them), device by device
-                rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, 0, 0);
+    for (;;) {
+        const uint32_t G = mode == MC_GROUP_SHARDS ? n / S : 1, n_act = mode == MC_GROUP_SHARDS ? S * G : n;
+        shard_kind = 0;
+        if (mode == MC_GROUP_REPLICAS) {
+            if (mz) rc = mcint::load_streamed(g->ctx.data(), n, F, 1);
+            if (!mz || (rc == MC_ENOMEM && !want_auto)) {
+                for (uint32_t m = 0; m < n; m++) {           // bucket-line tables (or the fallback to them), device by device
+                    rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, 0, 0);
+                    if (rc != MC_OK) break;
+                }
+            }
+        } else if (by_lines) {
+            shard_kind = 1;
+            rc = mcint::load_streamed(g->ctx.data(), n_act, F, S);
+        } else {
+            shard_kind = 2;                                   // the reference's own partition (CuClarkDB.cu:552-559)
+            for (uint32_t m = 0; m < n; m++) {
+                rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, g->htsize * m / n, g->htsize * (m + 1) / n);
                 if (rc != MC_OK) break;
             }
         }
-    } else if (mz && !(getenv("MC_GROUP_SHARD") && !strcmp(getenv("MC_GROUP_SHARD"), "buckets"))) {
-        shard_kind = 1;
-        rc = mcint::load_streamed(g->ctx.data(), n, F, true);
-    } else {
-        shard_kind = 2;                                   // the reference's own partition (CuClarkDB.cu:552-559)
-        for (uint32_t m = 0; m < n; m++) {
-            rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, g->htsize * m / n, g->htsize * (m + 1) / n);
-            if (rc != MC_OK) break;
+        // AUTO and the estimate was too kind (a table just under one card's HBM, a table whose lines overflow more
+        // than the estimate assumes): cut it into more parts instead of giving up
+        if (rc == MC_ENOMEM && want_auto && by_lines && S < n) {
+            mode = MC_GROUP_SHARDS;
+            uint32_t next = S + 1;
+            while (next < n && n / next == n / S) next++;                      // the next S that changes the group count
+            S = n / (n / next);
+            fprintf(stderr, "libmcclark: %s; cutting the table into %u parts\n", mc_last_error(), S);
+            continue;
         }
+        g->S = mode == MC_GROUP_SHARDS ? S : 1; g->G = mode == MC_GROUP_SHARDS ? G : n;
+        break;
     }
     if (rc == MC_ENOMEM)
         return fail(MC_ENOMEM, std::string("the database does not fit the ") + std::to_string(n) + " device(s) of the group (" +
@@ -246,7 +283,9 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
     g->info.bytes_needed_one = need_one;
     g->info.bytes_free_min = free_min;
     g->info.device_bytes_max = 0;
-    for (mc_ctx *c : g->ctx) g->info.device_bytes_max = std::max<uint64_t>(g->info.device_bytes_max, c->info.device_bytes);
+    g->info.n_shards = g->S; g->info.n_groups = g->G;
+    for (mc_ctx *c : g->ctx) if (c->db_loaded) g->info.device_bytes_max = std::max<uint64_t>(g->info.device_bytes_max, c->info.device_bytes);
+    g->last_on_slot.assign((size_t)g->G * 2, -1);
     g->loaded = true;
     return MC_OK;
 }
@@ -277,7 +316,7 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
     const uint32_t n = W(g);
     const bool shards = g->info.mode == MC_GROUP_SHARDS;
     g->max_reads = max_reads; g->max_con = max_con; g->want_rows = want_rows != 0;
-    g->per = (max_reads + n - 1) / n;
+    g->per = (max_reads + g->S - 1) / g->S;
     const size_t row_len = 2 * (size_t)g->maxhits + 2;
     auto oom = [&](const char *what, hipError_t e) {
         free_batches(g);
@@ -312,11 +351,12 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
     g->d_slab.assign(n, nullptr);
     const size_t d_ptr = up((max_reads + 1) * 4), d_con = up(max_con * 2);
     const size_t d_rows = shards ? up(max_reads * row_len * 2) : (g->want_rows ? up(max_reads * row_len * 2) : 0);
-    const size_t d_recv = shards ? up((size_t)(n > 1 ? n - 1 : 1) * g->per * row_len * 2) : 0;
+    const size_t d_recv = shards ? up((size_t)(g->S > 1 ? g->S - 1 : 1) * g->per * row_len * 2) : 0;
     const size_t d_fin = up((shards ? g->per : max_reads) * MC_FINAL_ROW * 2);
     const size_t d_mrg = shards && g->want_rows ? up(g->per * row_len * 2) : 0;
     const size_t per_slot = d_ptr + d_con + d_rows + d_recv + d_fin + d_mrg;
     for (uint32_t m = 0; m < n; m++) {
+        if (shards && m >= g->S * g->G) break;            // a member without a part of the table
         if ((rc = mcint::set_dev(g->ctx[m])) != MC_OK) { free_batches(g); return rc; }
         e = hipMalloc((void **)&g->d_slab[m], per_slot * 2);
         if (e != hipSuccess) return oom("device batch buffers", e);
@@ -364,6 +404,7 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
     const size_t row_len = 2 * (size_t)g->maxhits + 2;
     int rc;
 
+    if (!g->loaded) return fail(MC_ESTATE, "mc_group_submit before a database was loaded");
     if (g->info.mode != MC_GROUP_SHARDS) {
         // replicas: the batch goes to one member, through that context's three queues (copy in, compute, copy out)
         const uint32_t m = (uint32_t)(g->n_submitted++ % n);
@@ -373,29 +414,29 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
         if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
         rc = mcint::submit_batch(c, b.h_ptr, b.h_con, b.h_final, b.h_rows, n_reads, n_con, flags, b.done[m]);
         if (rc) return rc;
-        for (uint32_t o = 0; o < n; o++) {                 // every member's event is signalled: wait() needs no mode
-            if (o == m) continue;
-            if ((rc = mcint::set_dev(g->ctx[o])) != MC_OK) return rc;
-            HIPCHK(hipEventRecord(b.done[o], g->ctx[o]->streams[1]));
-        }
         (void)st; (void)si;
+        b.first = m; b.count = 1;
         b.submitted = true;
         return MC_OK;
     }
 
     // ---- shards ----------------------------------------------------------------------------------
-    const int si = (int)(g->n_submitted++ & 1u);
-    const int prev = g->last_on_slot[si];
-    g->last_on_slot[si] = (int)batch;
-    // every device: (slot free?) -> H2D -> rows of all reads for its share of the table
-    for (uint32_t m = 0; m < n; m++) {
-        mc_ctx *c = g->ctx[m];
-        GSlot &s = g->slots[(size_t)m * 2 + si];
+    // the batch goes to ONE group (round-robin over the G groups that each hold the whole table); inside the group
+    // every member sees it
+    const uint32_t S = g->S, gi = (uint32_t)(g->n_submitted % g->G), m0 = gi * S;
+    const int si = (int)((g->n_submitted / g->G) & 1u);
+    g->n_submitted++;
+    const int prev = g->last_on_slot[(size_t)gi * 2 + si];
+    g->last_on_slot[(size_t)gi * 2 + si] = (int)batch;
+    // every member of the group: (slot free?) -> H2D -> rows of all reads for its share of the table
+    for (uint32_t p = 0; p < S; p++) {
+        mc_ctx *c = g->ctx[m0 + p];
+        GSlot &s = g->slots[(size_t)(m0 + p) * 2 + si];
         hipStream_t st = c->streams[si];
         if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
         if (prev >= 0 && prev != (int)batch)                        // the owners pulled from this slot's rows
-            for (uint32_t j = 0; j < n; j++)
-                if (j != m) HIPCHK(hipStreamWaitEvent(st, g->batches[prev].done[j], 0));
+            for (uint32_t j = 0; j < S; j++)
+                if (j != p) HIPCHK(hipStreamWaitEvent(st, g->batches[prev].done[m0 + j], 0));
         if (n_reads) {
             HIPCHK(hipMemcpyAsync(s.d_ptr, b.h_ptr, (n_reads + 1) * 4, hipMemcpyHostToDevice, st));
             if (n_con) HIPCHK(hipMemcpyAsync(s.d_con, b.h_con, n_con * 2, hipMemcpyHostToDevice, st));
@@ -405,9 +446,9 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
         HIPCHK(hipEventRecord(s.ev_query, st));
     }
     // every owner: pull its read range from the others, merge, top-2, back to the host
-    for (uint32_t j = 0; j < n; j++) {
-        mc_ctx *c = g->ctx[j];
-        GSlot &s = g->slots[(size_t)j * 2 + si];
+    for (uint32_t j = 0; j < S; j++) {
+        mc_ctx *c = g->ctx[m0 + j];
+        GSlot &s = g->slots[(size_t)(m0 + j) * 2 + si];
         hipStream_t st = c->streams[si];
         if ((rc = mcint::set_dev(c)) != MC_OK) return rc;
         uint64_t lo, cnt;
@@ -415,16 +456,16 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
         if (cnt) {
             const uint16_t *srcs[mc::MERGE_MAX_SRCS];
             uint32_t r = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                GSlot &o = g->slots[(size_t)i * 2 + si];
+            for (uint32_t i = 0; i < S; i++) {
+                GSlot &o = g->slots[(size_t)(m0 + i) * 2 + si];
                 if (i == j) { srcs[i] = s.d_rows + lo * row_len; continue; }
                 HIPCHK(hipStreamWaitEvent(st, o.ev_query, 0));
                 uint16_t *dst = s.d_recv + (size_t)r * g->per * row_len;
-                HIPCHK(hipMemcpyPeerAsync(dst, c->device, o.d_rows + lo * row_len, g->ctx[i]->device, cnt * row_len * 2, st));
+                HIPCHK(hipMemcpyPeerAsync(dst, c->device, o.d_rows + lo * row_len, g->ctx[m0 + i]->device, cnt * row_len * 2, st));
                 srcs[i] = dst;
                 r++;
             }
-            rc = mcint::launch_merge_result(c, srcs, n, cnt, (flags & MC_F_ROWS) ? s.d_merged : nullptr,
+            rc = mcint::launch_merge_result(c, srcs, S, cnt, (flags & MC_F_ROWS) ? s.d_merged : nullptr,
                                             (flags & MC_F_FINAL) ? s.d_final : nullptr, st);
             if (rc) return rc;
             if (flags & MC_F_FINAL)
@@ -432,8 +473,9 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
             if (flags & MC_F_ROWS)
                 HIPCHK(hipMemcpyAsync(b.h_rows + lo * row_len, s.d_merged, cnt * row_len * 2, hipMemcpyDeviceToHost, st));
         }
-        HIPCHK(hipEventRecord(b.done[j], st));
+        HIPCHK(hipEventRecord(b.done[m0 + j], st));
     }
+    b.first = m0; b.count = S;
     b.submitted = true;
     return MC_OK;
 }
@@ -443,7 +485,7 @@ int mc_group_wait(mc_group *g, uint32_t batch)
     if (!g || batch >= g->batches.size()) return fail(MC_EINVAL, "bad batch index");
     GBatch &b = g->batches[batch];
     if (!b.submitted) return fail(MC_ESTATE, "batch was never submitted");
-    for (uint32_t m = 0; m < W(g); m++) {
+    for (uint32_t m = b.first; m < b.first + b.count; m++) {       // the members that worked on it
         int rc = mcint::set_dev(g->ctx[m]); if (rc) return rc;
         HIPCHK(hipEventSynchronize(b.done[m]));
     }

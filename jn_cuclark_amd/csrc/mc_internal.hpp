@@ -100,8 +100,8 @@ struct mc_ctx {
     // lines do not fit in HBM)
     int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
     uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
-    uint32_t mz_n_lines = 0;           // lines of the whole table (all parts)
-    uint32_t mz_line0 = 0, mz_n_local = 0, mz_m = 0;
+    uint32_t mz_n_local = 0;           // primary lines held here (every part of a table has the same number)
+    uint32_t mz_part = 0, mz_n_parts = 1, mz_m = 0;
     double fill_hint = 0.0;            // k-mers per line chosen by a group loader for all its members (0 = choose here)
     mcint::IndexBuild build;
 
@@ -152,12 +152,20 @@ struct DbFileStream {
 };
 
 // Build the minimizer index of every context from one stream of the files (each chunk is read once per
-// pass and fed to all contexts).  line_parts: context i owns line range i of n (a line-sharded table);
-// otherwise every context builds the whole [sb, se) range (replicas).  MC_ENOMEM when a context cannot
-// hold its lines.
-int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, bool line_parts);
+// pass and fed to all contexts).  Context i builds part i % n_parts of n_parts (n_parts = 1: every context
+// builds the whole [sb, se) range -- replicas; n > n_parts: several groups that each hold the whole table).
+// MC_ENOMEM when a context cannot hold its lines.
+int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts);
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total);
+// The arithmetic of the index plan (no device needed: mc_index_plan exposes it to tests).
+// lines_per_part: primary lines of ONE part at `fill` k-mers per line; 0 when that exceeds the 32-bit line index.
+uint64_t lines_per_part(uint64_t n_keys_total, uint32_t n_parts, double fill);
 uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill);
+// the sparsest fill in [4, 12] whose share fits `free_bytes` (16 GB kept in reserve) AND the line index
 double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes);
+// smallest part count in [1, max_parts] whose share fits at a fill of at most `max_fill`; 0 = none does
+uint32_t min_parts(uint64_t n_keys_total, uint32_t max_parts, uint64_t free_bytes, double max_fill);
+static constexpr uint64_t MZ_MAX_LINES = 0xFFFFFFF0ull;      // per context
+static constexpr uint64_t MZ_RESERVE_BYTES = 16ull << 30;    // left free next to the index (batch buffers, runtime)
 
 } // namespace mcint

@@ -13,7 +13,8 @@
 //
 //   K(c)    = min over the k-m+1 = MZ_MAXW (9) windows w of canonical k-mer c of key(min(w, rc(w)))
 //             (orientation-free: x and rc(x) have the same set of canonical m-mers)
-//   line(c) = mulhi(mix32(K(c)), n_lines)
+//   line(c) = mulhi(mix32(K(c)), lines per part)      part(c) = mulhi(mix32'(K(c)), n_parts)
+//             (two hashes of the 52-bit key: a table spread over G contexts addresses G x 2^32 lines)
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, ascending, unused = all ones last),
 //             12 labels (u16), dword30 = extra lines (bits 0-2) | spill flag (bit 3) | Bloom word
 //             over the k-mers that are not in the first line (high 16 bits), dword31 = first extra line
@@ -189,6 +190,19 @@ __device__ __forceinline__ uint32_t line_of(uint64_t K, uint32_t n_lines)
     return __umulhi(h, n_lines);
 }
 
+// A table that is spread over several contexts (GPUs): WHICH of them owns the k-mers of a minimizer is drawn
+// from a second hash of the key, the line inside that context's share from line_of() -- every part has the same
+// number of lines.  Round 2 cut ONE 32-bit line space into ranges: n_keys / fill lines in all, so a table of
+// 32e9 k-mers (8 cards x 4e9) could not be loaded at the sparse fills the cards had room for.  Two hashes of
+// the 52-bit key address n_parts x 2^32 lines; the 32-bit limit is now per context (550 GB of lines: never).
+// The second hash must bring bits the first does not have (the part drawn from line_of()'s own hash would leave
+// 7 of 8 lines of a part without any minimizer): low word times a constant plus the high word, 2 VALU ops.
+__device__ __forceinline__ uint32_t part_of(uint64_t K, uint32_t n_parts)
+{
+    const uint32_t h = (uint32_t)K * 0x85EBCA6Bu + (uint32_t)(K >> 32);
+    return __umulhi(h, n_parts);
+}
+
 // A line's header (dword 30) = number of extra lines (bits 0-2) | spill flag (bit 3) | a 16-bit Bloom
 // word (high half) over the k-mers that live in those extra lines, two bits per k-mer (an overflowing line spills 1-3 k-mers as
 // a rule: 2-5 % false positives instead of 6-17 % with one bit).  A k-mer that is not in the first line
@@ -231,7 +245,7 @@ template <int PASS, bool WIDE>
 __global__ __launch_bounds__(RL_THREADS)
 void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, const uint16_t *labels,
                      uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const uint64_t *blk_key_off,
-                     uint32_t k, uint32_t m, uint32_t n_lines_total, uint32_t line0, uint32_t n_local,
+                     uint32_t k, uint32_t m, uint32_t part, uint32_t n_parts, uint32_t n_local,
                      uint32_t *count, uint8_t *lines, uint8_t *extra_lines, unsigned int *failed)
 {
     __shared__ uint32_t s_a[RL_THREADS / 64];
@@ -246,8 +260,9 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
         if (b >= n_buckets) break;
         for (uint32_t j = 0; j < cnt[i]; j++) {
             const uint64_t c = (uint64_t)keys[koff + j] * htsize + (bucket0 + b);     // the canonical k-mer
-            const uint32_t l = line_of(kmer_min_key(c, k, m), n_lines_total) - line0;
-            if (l >= n_local) continue;                                               // another shard's line
+            const uint64_t K = kmer_min_key(c, k, m);
+            if (n_parts > 1u && part_of(K, n_parts) != part) continue;               // another part's k-mer
+            const uint32_t l = line_of(K, n_local);
             const uint32_t slot = atomicAdd(&count[l], 1u);       // PASS 1: the counters were reset; they end equal to PASS 0's
             if (PASS == 1) {
                 uint8_t *first = lines + (uint64_t)l * MZ_LINE;
@@ -261,6 +276,9 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
                     const uint32_t seg_log = (h0 >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK;
                     uint8_t *chain0 = extra_lines + (uint64_t)hdr[1] * MZ_LINE;
                     if (seg_log == 0u) {                               // one chain, filled in arrival order
+                        // The chain was sized from PASS 0's count of this line.  A second pass that is not the
+                        // first one again (another table, a file that changed) must not write past it.
+                        if (slot >= (uint32_t)MZ_CAP * (1u + (h0 & MZ_HDR_LEN))) { atomicOr(failed, 2u); continue; }
                         const uint32_t e = slot - MZ_CAP;
                         uint8_t *base = chain0 + (uint64_t)(e / MZ_CAP) * MZ_LINE;
                         reinterpret_cast<uint64_t *>(base)[e % MZ_CAP] = c;
@@ -535,8 +553,8 @@ struct MzArgs {
     QueryArgs q;               // reads, outputs, shard range, div, k, maxhits, flags (lines unused)
     const uint8_t *lines;      // the primary lines this context owns
     const uint8_t *extra;      // extra lines
-    uint32_t n_lines;          // lines the whole table is spread over (all shards)
-    uint32_t line0, n_local;   // this context owns lines [line0, line0 + n_local)
+    uint32_t n_lines;          // primary lines of THIS context (every part of a table has the same number)
+    uint32_t part, n_parts;    // MZ_LINES: this context answers for the minimizers with part_of(K) == part
     uint32_t m;
     double inv_htsize;         // 1/HTSIZE when the bucket-range filter may use rem_u64_fp, else 0
 };
@@ -545,7 +563,7 @@ struct MzArgs {
 enum { MZ_ALL = 0,             // the whole table
        MZ_BUCKETS = 1,         // k-mers of a bucket range [shard_begin, shard_end) of the reference's hash
                                // (CuClarkDB.cu:552-559, :1212-1214): every shard fetches nearly every line
-       MZ_LINES = 2 };         // k-mers of a LINE range: a shard fetches, matches and scores 1/G of the runs
+       MZ_LINES = 2 };         // the k-mers of 1/G of the MINIMIZERS (part_of): a part fetches, matches and scores 1/G of the runs
 
 // One lane against one 128-byte line parked in LDS.  The keys of a first line are in ascending order
 // (mz_sort_lines_kernel; unused slots = all ones last), so the 7th key says which half of the line can hold
@@ -860,18 +878,25 @@ void mz_query_kernel(const MzArgs A)
                         line[1] = line_of(K1, A.n_lines);
                         uint64_t own0 = in0, own1 = in1;
                         if constexpr (SHARD == MZ_LINES) {
-                            // local line index; k-mers of lines this context does not own drop out here,
-                            // and only owned runs are numbered (fetched, matched, scored)
-                            line[0] -= A.line0;
-                            line[1] -= A.line0;
-                            own0 &= mask_lt_s(line[0], A.n_local);
-                            own1 &= mask_lt_s(line[1], A.n_local);
+                            // k-mers whose minimizer belongs to another part drop out here, and only owned
+                            // runs are numbered (fetched, matched, scored).  Two runs of one read that differ in
+                            // part but collide in the line index are told apart by ownership: a run is a
+                            // maximal stretch of OWNED positions with one line.
+                            own0 &= mask_eq_s(part_of(K0, A.n_parts), A.part);
+                            own1 &= mask_eq_s(part_of(K1, A.n_parts), A.part);
                             active[0] = __builtin_amdgcn_inverse_ballot_w64(own0);
                             active[1] = __builtin_amdgcn_inverse_ballot_w64(own1);
                         }
                         // second line of the lane before (DPP wave_shr:1); nothing before lane 0
                         const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)line[1], 0x138, 0xf, 0xf, false);
-                        const uint64_t b0 = mask_ne(line[0], prev) & own0, b1 = mask_ne(line[1], line[0]) & own1;
+                        uint64_t b0 = mask_ne(line[0], prev), b1 = mask_ne(line[1], line[0]);
+                        if constexpr (SHARD == MZ_LINES) {
+                            // line indexes are per part: the position before may show the same index and belong
+                            // to another part's line -- an owned position behind one that is not owned leads a run
+                            b0 |= ~(own1 << 1);
+                            b1 |= ~own0;
+                        }
+                        b0 &= own0; b1 &= own1;
                         own[0] = own0; own[1] = own1;
                         leader[0] = __builtin_amdgcn_inverse_ballot_w64(b0);
                         leader[1] = __builtin_amdgcn_inverse_ballot_w64(b1);

@@ -23,7 +23,10 @@ Rows are exact integers, so the result is bit-identical to the unsharded run for
 
 `Replica` mode (table on every GPU, reads split) needs no exchange at all and is the throughput-optimal
 choice whenever the table fits one GPU (288 GB): every part still encodes every read and finds its
-minimizers.
+minimizers.  In between: a table that needs S cards is cut into S parts -- as few as memory dictates, the
+reference's minParts (src/CuClarkDB.cu:529-559) -- and the world forms G = world // S groups that each hold
+the whole table and classify their own batches (plan_shards, shard_groups below): the exchange stays inside
+a group, and only S, not world, GPUs repeat the front half of the kernel for a read.
 """
 import torch
 import torch.distributed as dist
@@ -39,6 +42,34 @@ def read_range(n_reads, rank, world):
     per = (n_reads + world - 1) // world
     lo = min(n_reads, rank * per)
     return lo, min(n_reads, lo + per), per
+
+
+def plan_shards(n_keys_total, world, hbm_bytes):
+    """(S, G): parts the table is cut into and groups of S ranks that each hold all of it.  S = the smallest part
+    count whose share fits `hbm_bytes` per GPU at an acceptable fill (mc_index_plan: the arithmetic mc_group_load_db
+    uses), spread evenly: G = world // S_min groups of S = world // G ranks; ranks past S * G stay idle.  A table
+    that fits no way gets one group of `world` parts (the load will say so)."""
+    from . import _lib
+    s_min = _lib.index_plan(n_keys_total, 1, hbm_bytes)["min_parts"]
+    if s_min < 1 or s_min > world:
+        return world, 1
+    G = world // s_min
+    return world // G, G
+
+
+def shard_groups(n_shards, world=None, rank=None):
+    """Process groups of `n_shards` consecutive ranks.  EVERY rank of the world must call this (new_group is
+    collective).  Returns (group, group_index, part, n_groups); group is None for a rank past the last full group."""
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    G = max(1, world // n_shards)
+    mine = None
+    for g in range(G):
+        h = dist.new_group(ranks=list(range(g * n_shards, (g + 1) * n_shards)))
+        if g * n_shards <= rank < (g + 1) * n_shards:
+            mine = h
+    gi = rank // n_shards
+    return (mine, gi, rank % n_shards, G) if gi < G else (None, -1, -1, G)
 
 
 def chunk_bounds(n_reads, n_chunks):

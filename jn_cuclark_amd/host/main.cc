@@ -187,8 +187,9 @@ struct Classifier {
             mc_get_db_info(c0, &info);
             std::cerr << "Devices: " << gi.n_members << " ("
                       << (gi.mode == MC_GROUP_SHARDS ? (gi.shard_kind == 1 ? "shards by minimizer line range" : "shards by bucket range")
-                                                     : "replicas")
-                      << ", peer access " << (gi.peer_access ? "yes" : "no") << ")\n";
+                                                     : "replicas");
+            if (gi.mode == MC_GROUP_SHARDS) std::cerr << ": " << gi.n_shards << " parts x " << gi.n_groups << " groups";
+            std::cerr << ", peer access " << (gi.peer_access ? "yes" : "no") << ")\n";
             std::cerr << "Total DB size in HBM:\t" << gi.device_bytes_max / 1000000 / 1000.0 << " GB per device (" << gi.n_keys
                       << " k-mers, " << (info.index_kind == MC_INDEX_MINIMIZER ? "minimizer index" : "bucket-line table")
                       << (info.index_fallback ? " [fallback: the minimizer index did not fit]" : "") << ", " << info.line_bytes

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from jn_cuclark_amd import synth                                    # noqa: E402
-from jn_cuclark_amd.dist import ShardedClassifier, shard_range, dense_allreduce_classify      # noqa: E402
+from jn_cuclark_amd.dist import ShardedClassifier, shard_range, shard_groups, dense_allreduce_classify      # noqa: E402
 from oracle import pyoracle                                         # noqa: E402
 from helpers import small_db                                        # noqa: E402
 
@@ -43,19 +43,25 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     genomes, sz, ky, lb = small_db(n_targets=10)
-    codes, _ = synth.sample_reads(genomes, n_reads, 150, seed=6)
-    rp, con = synth.pack_uniform(codes)
     odb = pyoracle.OracleDB.from_arrays(HT, sz, ky, lb)
-    sc = ShardedClassifier(OracleBackend(odb, shard_range(HT, rank, world)), n_chunks=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
-    fin = sc.classify_gathered(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
-    part, ranges = sc.classify(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
-    assert torch.equal(part, torch.cat([fin[lo:hi] for lo, hi in ranges]))
-    # the dense all-reduce of per-target vectors (BASELINE's wording of the combine) gives the same rows
-    dense = dense_allreduce_classify(sc.be, torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads, 10)
-    assert torch.equal(dense, fin)
-    if rank == 0:
-        want, _ = odb.classify(K, rp, con, MAXHITS)
-        np.savez(out, got=fin.numpy().view(np.uint16), want=want)
+    # S parts x G groups (argv[4], default: one group of `world` parts).  Every group holds the whole table and
+    # classifies ITS OWN batch (seed 6 + group); the exchange stays inside the group.
+    S = int(sys.argv[4]) if len(sys.argv) > 4 else world
+    group, gi, part_i, G = shard_groups(S)
+    if group is not None:
+        codes, _ = synth.sample_reads(genomes, n_reads, 150, seed=6 + gi)
+        rp, con = synth.pack_uniform(codes)
+        sc = ShardedClassifier(OracleBackend(odb, shard_range(HT, part_i, S)), group=group, n_chunks=int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+        assert sc.world == S and sc.rank == part_i
+        fin = sc.classify_gathered(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
+        part, ranges = sc.classify(torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads)
+        assert torch.equal(part, torch.cat([fin[lo:hi] for lo, hi in ranges]))
+        # the dense all-reduce of per-target vectors (BASELINE's wording of the combine) gives the same rows
+        dense = dense_allreduce_classify(sc.be, torch.from_numpy(rp.view(np.int32)), torch.from_numpy(con.view(np.int16)), n_reads, 10, group=group)
+        assert torch.equal(dense, fin)
+        if part_i == 0:
+            want, _ = odb.classify(K, rp, con, MAXHITS)
+            np.savez(out if gi == 0 else out + ".g%d.npz" % gi, got=fin.numpy().view(np.uint16), want=want)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -64,3 +64,61 @@ def test_fails_loudly_without_gpu():
     from jn_cuclark_amd import CuClarkDB, McError
     with pytest.raises(McError):
         CuClarkDB(k=31, numBatches=1, numTargets=3)
+
+
+GB = 1 << 30
+CARD = 288 * 10**9          # one MI355X
+
+
+@pytest.mark.parametrize("n_keys", [6_450_000_000, 20_000_000_000, 32_000_000_000, 50_000_000_000, 90_000_000_000])
+def test_index_plan_respects_the_line_space_and_the_budget(n_keys):
+    """The loader's arithmetic without a device (mc_index_plan = choose_fill / lines_per_part / min_parts of
+    csrc/mc_api.hip).  Round 2 computed n_keys / fill GLOBAL lines in 32 bits: 32e9 k-mers over 8 cards came out at
+    fill 4 = 8e9 lines = "too many lines".  A part now has its own 32-bit line space (mc_minimizer.hpp part_of):
+    every table whose share fits a card's HBM must come out with a plan.  Reference behaviour: a table is cut
+    into as many parts as memory dictates and runs whatever its size (src/CuClarkDB.cu:516-559)."""
+    from jn_cuclark_amd import _lib
+    if not os.path.exists(_lib.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    for n_parts in range(1, 9):
+        p = _lib.index_plan(n_keys, n_parts, CARD)
+        assert 4.0 <= p["fill"] <= 12.0
+        share = n_keys / n_parts
+        if p["fits"]:
+            assert 0 < p["lines_per_part"] < 0xFFFFFFF0
+            assert p["bytes_per_part"] + 16 * GB <= CARD
+            # the lines really hold the part's k-mers at that fill (+ the 1024 lines of slack, rounded up)
+            assert p["lines_per_part"] * n_parts * p["fill"] >= n_keys
+            assert p["lines_per_part"] * p["fill"] <= share + 1024 * p["fill"] + p["fill"] * n_parts
+        else:
+            # does not fit even at 12 per line: more than ~12e9 k-mers per card
+            assert share > 11e9, (n_keys, n_parts, p)
+        # the sparsest fill is taken: one step sparser would not fit (or we are at 4)
+        if p["fits"] and p["fill"] > 4.0:
+            q = _lib.index_plan(n_keys, n_parts, CARD - 1)      # monotone in the budget
+            assert q["fill"] >= p["fill"]
+    p8 = _lib.index_plan(n_keys, 8, CARD)
+    assert p8["fits"] == 1, "8 cards hold up to 90e9 k-mers"
+    # the smallest part count: one less must not fit at fill 10, and the count itself does
+    s = p8["min_parts"]
+    assert 1 <= s <= 8
+    assert _lib.index_plan(n_keys, s, CARD)["fits"] == 1
+    if s > 1:
+        lower = _lib.index_plan(n_keys, s - 1, CARD)
+        assert lower["fits"] == 0 or lower["fill"] > 10.0
+
+
+def test_index_plan_examples_of_the_review():
+    """configs[3]/[4] scale: 32e9 k-mers.  8 cards: fill 4, 1.0e9 lines each; one card cannot hold it; the
+    line limit itself (2^32 - 16 lines per part) is only reached beyond what any card holds."""
+    from jn_cuclark_amd import _lib
+    p = _lib.index_plan(32_000_000_000, 8, CARD)
+    assert p["fits"] == 1 and p["fill"] == 4.0 and p["lines_per_part"] == (32_000_000_000 // 4 + 1024 + 7) // 8
+    assert p["min_parts"] == 3                                        # 32e9 / 3 = 10.7e9 per card at 10 per line
+    assert _lib.index_plan(32_000_000_000, 1, CARD)["fits"] == 0
+    assert _lib.index_plan(32_000_000_000, 4096, CARD)["fits"] == 1    # part 0 of 4096: a few MB
+    # a budget with room for more than 2^32 lines: the fill is clamped by the line space, not refused
+    huge = _lib.index_plan(40_000_000_000, 1, 4000 * 10**9)
+    assert huge["fits"] == 1 and huge["fill"] > 9.0 and huge["lines_per_part"] < 0xFFFFFFF0
+    assert _lib.index_plan(6_450_000_000, 1, CARD)["min_parts"] == 1

@@ -25,6 +25,36 @@ def test_sharded_protocol_on_gloo(world, n_reads, chunks, tmp_path):
     assert np.array_equal(d["got"], d["want"])
 
 
+@pytest.mark.parametrize("world,shards", [(4, 2), (5, 2)])
+def test_shard_groups_on_gloo(world, shards, tmp_path):
+    """S parts x G groups: a table that needs `shards` cards, `world` ranks -> world // shards groups that each hold
+    the whole table and classify their own batch; a rank past the last full group stays idle (5 ranks, 2 parts)"""
+    out = str(tmp_path / "res.npz")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29650 + world),
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, "301", "3", str(shards)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = []
+    for g in range(world // shards):
+        d = np.load(out if g == 0 else out + ".g%d.npz" % g)
+        assert d["got"].shape == (301, 5) and np.array_equal(d["got"], d["want"])
+        seen.append(d["got"])
+    assert len(seen) == 2 and not np.array_equal(seen[0], seen[1])        # the groups worked on different batches
+
+
+def test_plan_shards():
+    from jn_cuclark_amd.dist import plan_shards
+    card = 288 * 10**9
+    assert plan_shards(6_450_000_000, 8, card) == (1, 8)            # fits one card: replicas
+    assert plan_shards(16_000_000_000, 8, card) == (2, 4)           # needs two: 4 groups of 2
+    assert plan_shards(32_000_000_000, 8, card) == (4, 2)           # needs three: 2 groups, spread over 4 each
+    assert plan_shards(60_000_000_000, 8, card) == (8, 1)
+    assert plan_shards(16_000_000_000, 7, card) == (2, 3)           # one rank idle
+    assert plan_shards(10**12, 8, card) == (8, 1)                   # fits no way: one group, the load says so
+
+
 def test_ranges_cover_everything():
     from jn_cuclark_amd.dist import shard_range, read_range
     for world in (1, 2, 3, 8):

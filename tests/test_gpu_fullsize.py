@@ -118,3 +118,44 @@ def test_eight_shards_with_paired_250bp_reads_equal_unsharded(world):
         db.result_rows_device(acc, out, n, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     assert torch.equal(out, fin_t)
+
+
+def test_eight_minimizer_parts_with_paired_250bp_reads_equal_unsharded(world):
+    """The same with the DEFAULT partition of a sharded table: 8 parts by minimizer (mc_index_begin(part, 8):
+    every part streams the whole table and keeps the k-mers whose minimizer hashes to it), played in turn on
+    the one card; every part sees every 2 x 250 bp pair; ONE k-way merge + top-2 over the 8 row sets (what the
+    owner of a read range runs after the exchange) == the fused single-table result."""
+    import torch
+    from jn_cuclark_amd import CuClarkDB, synth_gpu
+    dev, genomes, raw, _ = world
+    n = 200_000
+    p1, c1 = synth_gpu.make_reads(genomes, n, 250, seed=521)
+    _, c2 = synth_gpu.make_reads(genomes, n, 250, seed=522)
+    per = c1.numel() // n
+    con = torch.cat([c1.view(n, per), c2.view(n, per)], dim=1).reshape(-1).contiguous()
+    rp = (torch.arange(n + 1, device=dev, dtype=torch.int64) * (2 * per)).to(torch.int32)
+    fin_t, _ = _classify(dev, raw, (rp, con, None, n))
+    d_sz, d_keys, d_labels = raw
+    n_keys = int(d_keys.numel())
+    st = torch.cuda.current_stream().cuda_stream
+    parts, owned, lines = [], 0, None
+    for p in range(8):
+        with CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=15) as db:
+            db.read_chunks(lambda: [(d_sz, d_keys, d_labels, 0, HT)], n_keys, part=p, n_parts=8, device=True)
+            info = db.db_info()
+            assert info["part"] == p and info["n_parts"] == 8 and info["n_keys"] == n_keys
+            assert lines is None or lines == info["line_end"] - info["line_begin"]       # every part: the same line count
+            lines = info["line_end"] - info["line_begin"]
+            owned += info["n_keys_owned"]
+            assert 0.11 < info["n_keys_owned"] / n_keys < 0.14                            # an eighth each
+            rows = torch.zeros((n, db.row_len), dtype=torch.int16, device=dev)
+            db.query_device(rp, con, rows_t=rows, stream=st)
+            torch.cuda.synchronize()
+            parts.append(rows)
+    assert owned == n_keys
+    with CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=15) as db:
+        out = torch.zeros((n, 5), dtype=torch.int16, device=dev)
+        db.merge_result_device(parts, n, final_t=out, stream=st)
+        torch.cuda.synchronize()
+    assert torch.equal(out, fin_t)
+    assert all(int((p_[:, 0] != 0).sum()) > n // 4 for p_ in parts)                     # every part contributes

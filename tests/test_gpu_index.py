@@ -203,3 +203,63 @@ def test_one_minimizer_shared_by_100000_kmers_is_spread_over_hashed_chains(gpu, 
     assert np.array_equal(got, oracle.result_rows(want_rows))
     n_hit = (stored[::3].size + stored[1::50].size)
     assert int((got[:q.size, 2] > 0).sum()) == n_hit
+
+
+@pytest.mark.parametrize("part,n_parts", [(0, 4096), (5, 8)])
+def test_a_part_of_a_table_that_needs_sharding_gets_its_lines(gpu, part, n_parts):
+    """configs[3]/[4] scale: 32e9 k-mers.  Round 2 refused this ("too many lines": 8e9 global lines in a 32-bit
+    index); a part now has a line space of its own.  The part is opened, fed an empty bucket range in both passes
+    and closed: fill, line count and HBM are what mc_index_plan says for a card of this size (part 5 of 8 really
+    allocates its 128 GB of lines).  Reference: a table is cut into as many parts as memory dictates and runs
+    whatever its size (src/CuClarkDB.cu:516-559)."""
+    import torch
+    from jn_cuclark_amd import _lib
+    n_keys = 32_000_000_000
+    total = torch.cuda.get_device_properties(0).total_memory
+    plan = _lib.index_plan(n_keys, n_parts, total)
+    assert plan["fits"] == 1 and plan["fill"] == 4.0
+    empty = (np.zeros(4096, dtype=np.uint8), np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint16), 0, 4096)
+    with gpu(k=31, numBatches=1, numTargets=8192, device=0, htsize=1610612741, maxhits=15) as db:
+        db.read_chunks(lambda: [empty], n_keys, part=part, n_parts=n_parts)
+        info = db.db_info()
+        assert info["index_kind"] == 1 and info["part"] == part and info["n_parts"] == n_parts
+        assert info["line_end"] - info["line_begin"] == plan["lines_per_part"] and info["line_begin"] == part * plan["lines_per_part"]
+        assert info["n_lines"] == plan["lines_per_part"] * n_parts > 2 ** 32        # more lines than one 32-bit space
+        assert info["device_bytes"] == (plan["lines_per_part"] + 1) * 128 or info["device_bytes"] == plan["lines_per_part"] * 128
+        assert info["n_keys_owned"] == 0
+        # and it answers (nothing stored: no hits)
+        got = db.classify(np.array([0, 21], dtype=np.uint32), np.concatenate([[150], np.arange(20)]).astype(np.uint16))
+        assert np.array_equal(got, np.zeros((1, 5), dtype=np.uint16))
+
+
+def test_a_second_pass_with_other_kmers_is_refused_not_written_out_of_bounds(gpu, oracle):
+    """The placing pass trusts the counts of the first.  Same NUMBER of k-mers, other k-mers (a generator that is not
+    deterministic, a file that changed): a line that outgrows the chain sized for it sets a flag instead of
+    writing past its extra lines; mc_index_end reports MC_EINVAL."""
+    from jn_cuclark_amd import McError
+    k, ht, m = 21, 1000003, 13
+    rng = np.random.default_rng(11)
+    n = 60000
+    a = np.unique(synth.canonical(rng.integers(0, 1 << (2 * k), size=n + 500, dtype=np.uint64), k))[:n]
+    # n k-mers around ONE m-mer: they all share its minimizer line
+    X = np.uint64(rng.integers(0, 1 << (2 * m)))
+    free = rng.choice(1 << 16, size=n + 500, replace=False).astype(np.uint64)
+    b = np.unique(synth.canonical(((free >> np.uint64(8)) << np.uint64(2 * m + 8)) | (X << np.uint64(8)) | (free & np.uint64(0xFF)), k))
+    assert b.size >= 40000
+    b = np.concatenate([b, a])[:n]
+    lab = np.zeros(n, dtype=np.uint16)
+    ta, tb = synth.db_from_kmers(a, lab, ht), synth.db_from_kmers(b, lab, ht)
+    state = {"n": 0}
+
+    def chunks():
+        state["n"] += 1
+        sz, ky, lb = ta if state["n"] == 1 else tb
+        yield sz, ky, lb, 0, ht
+
+    with gpu(k=k, numBatches=1, numTargets=1, device=0, htsize=ht, maxhits=15) as db:
+        with pytest.raises(McError) as e:
+            db.read_chunks(chunks, n)
+        assert "second pass" in str(e.value)
+        # the context is usable afterwards
+        db.read_arrays(*ta)
+        assert db.db_info()["n_keys"] == n

@@ -220,14 +220,70 @@ def test_reference_built_tables_against_reference_find(gpu, oracle, golden_dir, 
     for j in range(k):
         codes[:, j] = ((q >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)).astype(np.uint8)
     rp, con = synth.pack_uniform(codes)
+    found = g["query_found"].astype(bool)
+    qlab = g["query_label"].astype(np.int64)
+    per = 1000                                   # k-mers per long read
+    n_long = q.size // per
+    perm = np.random.default_rng(5).permutation(q.size)      # the fixture lists its k-mers target by target: mix them
     with _open(gpu, sz, g["keys"], g["labels"], k=k, ht=ht, maxhits=maxhits, ntargets=3) as db:
         got = db.classify(rp, con)
-        # the same k-mers as ONE long read per 1000 (consecutive positions share minimizers / steps)
-    found = g["query_found"].astype(bool)
+        # (2) the same k-mers as long reads of 1000 PARTS each ('N' between the k-mers: a part = one k-mer), so the
+        #     per-target sums of the reference's answers are the expected counts: multi-part reads, the accumulator
+        part = con.reshape(q.size, -1)[perm]                 # [k][containers] per k-mer
+        words = part.shape[1]
+        rp_n = (np.arange(n_long + 1, dtype=np.uint64) * np.uint64(per * words)).astype(np.uint32)
+        got_n = db.classify(rp_n, part[: n_long * per].reshape(-1))
+        # (3) ... and as ONE part per long read (the k-mers back to back, no 'N'): consecutive positions share
+        #     minimizers, lines, runs and steps; the k - 1 k-mers across every junction are looked up in the
+        #     reference-built table here, in numpy
+        long_codes = codes[perm][: n_long * per].reshape(n_long, per * k)
+        rp_c, con_c = synth.pack_uniform(long_codes)
+        got_c = db.classify(rp_c, con_c)
     assert found.sum() > 5000 and (~found).sum() > 5000
     assert np.array_equal(got[:, 2] > 0, found)
     assert np.array_equal(got[found, 1] - 1, g["query_label"][found])
     assert np.all(got[found, 0] == 1)
+
+    def final_of(counts):        # [n, T] hit counts -> the 5 result columns (ascending scan, strict '>': CuClarkDB.cu:1380-1397)
+        out = np.zeros((counts.shape[0], 5), dtype=np.uint16)
+        out[:, 0] = counts.sum(axis=1) & 0xFFFF
+        best = counts.argmax(axis=1)                       # first maximum = smallest id
+        bc = counts[np.arange(counts.shape[0]), best]
+        rest = counts.copy()
+        rest[np.arange(counts.shape[0]), best] = -1
+        sec = rest.argmax(axis=1)
+        sc = rest[np.arange(counts.shape[0]), sec]
+        out[:, 1] = np.where(bc > 0, best + 1, 0)
+        out[:, 2] = bc
+        out[:, 3] = np.where(sc > 0, sec + 1, 0)
+        out[:, 4] = np.maximum(sc, 0)
+        return out
+
+    T = 3
+    cnt = np.zeros((n_long, T), dtype=np.int64)
+    f_l, l_l = found[perm][: n_long * per].reshape(n_long, per), qlab[perm][: n_long * per].reshape(n_long, per)
+    for t in range(T):
+        cnt[:, t] = (f_l & (l_l == t)).sum(axis=1)
+    assert cnt.sum() == f_l.sum() and (cnt > 50).all()            # every long read hits all three targets
+    assert np.array_equal(got_n, final_of(cnt))
+    # junction k-mers of (3): every position of the long read that is not a multiple of k
+    nzb = g["nonzero_buckets"].astype(np.uint64)
+    canon_db = np.repeat(nzb, g["nonzero_sizes"]) + g["keys"].astype(np.uint64) * np.uint64(ht)
+    order = np.argsort(canon_db)
+    canon_sorted, lab_sorted = canon_db[order], g["labels"].astype(np.int64)[order]
+    cnt_c = cnt.copy()
+    extra = 0
+    for r in range(n_long):
+        km = synth.canonical(synth.kmers_of(long_codes[r], k), k)
+        pos = np.arange(km.size)
+        km = km[pos % k != 0]
+        at = np.searchsorted(canon_sorted, km)
+        at[at >= canon_sorted.size] = 0
+        hit = canon_sorted[at] == km
+        extra += int(hit.sum())
+        for t in range(T):
+            cnt_c[r, t] += int((hit & (lab_sorted[at] == t)).sum())
+    assert np.array_equal(got_c, final_of(cnt_c))
 
 
 def test_file_loader_and_sampling(gpu, oracle, tmp_path):

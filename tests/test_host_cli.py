@@ -664,6 +664,9 @@ def test_fast_g_format_matches_printf(tmp_path):
     ("0,0,0", {"MC_GROUP_MODE": "shards", "MC_GROUP_SHARD": "buckets"}, "shards by bucket range"),
     ("0,0", {"MC_GROUP_MODE": "shards", "MC_INDEX": "lines"}, "shards by bucket range"),
     ("0,0,0", {}, "replicas"),
+    # as few parts as the budget dictates, replicated: 4 members, a table that needs 2 -> 2 parts x 2 groups
+    ("0,0,0,0", {"MC_GROUP_HBM_BYTES": "fit2"}, "shards by minimizer line range: 2 parts x 2 groups"),
+    ("0,0,0,0,0", {"MC_GROUP_MODE": "shards", "MC_GROUP_PARTS": "2"}, "shards by minimizer line range: 2 parts x 2 groups"),
 ])
 @pytest.mark.parametrize("extended", [False, True])
 def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members, env, expect, extended):
@@ -693,11 +696,27 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
                          capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr
     assert "Devices: 1 (replicas" in one.stderr
+    if env.get("MC_GROUP_HBM_BYTES") == "fit2":
+        # a per-device budget that holds half of this table but not all of it (mc_index_plan is the loader's
+        # own arithmetic: min_parts must come out as 2); the database was built by the run above
+        from jn_cuclark_amd import _lib
+        n_keys = os.path.getsize(str(dbdir / ("db_central_k27_t6_s%d_m0_light_4.tsk.ky" % ht))) // 4
+        lo, hi = 1 << 30, 64 << 30
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if 1 <= _lib.index_plan(n_keys, 1, mid)["min_parts"] <= 2:
+                hi = mid
+            else:
+                lo = mid
+        assert _lib.index_plan(n_keys, 1, hi)["min_parts"] == 2
+        env = dict(env, MC_GROUP_HBM_BYTES=str(hi))
     e = dict(os.environ, MC_GROUP_DEVICES=members, **env)
     many = subprocess.run([os.path.join(BIN, "cuCLARK-l")] + common + ["-R", str(tmp_path / "many")],
                           capture_output=True, text=True, timeout=900, env=e)
     assert many.returncode == 0, many.stderr
     assert ("Devices: %d (%s" % (len(members.split(",")), expect)) in many.stderr, many.stderr
+    if "replicas" not in expect and "parts x" not in expect:
+        assert ("%d parts x 1 groups" % len(members.split(","))) in many.stderr, many.stderr
     a, b = open(str(tmp_path / "one.csv")).read(), open(str(tmp_path / "many.csv")).read()
     assert a == b
     base = str(dbdir / ("db_central_k27_t6_s%d_m0_light_4.tsk" % ht))
