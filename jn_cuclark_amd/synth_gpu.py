@@ -71,15 +71,39 @@ def make_genomes(n_targets, length, seed, device):
     return torch.randint(0, 4, (n_targets, length), dtype=torch.uint8, device=device, generator=g)
 
 
-def build_db(device, seed, k, htsize, n_targets, lam, genomes=None, shard=None):
-    """Returns (d_sz uint8[nb], d_keys int32[n], d_labels int16[n]) for buckets `shard`."""
+def genome_kmers_by_bucket(genomes, k, htsize):
+    """(r, q, label) of every k-mer of the genomes, sorted by bucket r: what build_db appends to the background,
+    computed once (a caller that generates the table range by range, pass after pass, hands it back as `appended`)"""
+    device = genomes.device
+    km = kmers_t(genomes, k)
+    lab = torch.arange(genomes.shape[0], device=device, dtype=torch.int16)[:, None].expand_as(km).reshape(-1)
+    km = km.reshape(-1)
+    c = torch.minimum(km, revcomp_t(km, k))
+    del km
+    r = c % htsize
+    r, order = torch.sort(r)
+    q = (c // htsize)[order]
+    del c
+    lab = lab[order]
+    del order
+    return r.contiguous(), q.contiguous(), lab.contiguous()
+
+
+def build_db(device, seed, k, htsize, n_targets, lam, genomes=None, shard=None, appended=None, count_only=False):
+    """Returns (d_sz uint8[nb], d_keys int32[n], d_labels int16[n]) for buckets `shard`
+    (count_only: just the number of k-mers)."""
     lib = _syn()
     b0, b1 = shard if shard else (0, htsize)
     nb = b1 - b0
     stream = torch.cuda.current_stream(device).cuda_stream
     app_r = app_q = app_l = None
     n_app = 0
-    if genomes is not None:
+    if appended is not None:
+        r, q, lab = appended
+        lo, hi = (int(v) for v in torch.searchsorted(r, torch.tensor([b0, b1], device=device, dtype=r.dtype)).tolist())
+        app_r, app_q, app_l = r[lo:hi], q[lo:hi], lab[lo:hi]          # contiguous slices
+        n_app = hi - lo
+    elif genomes is not None:
         km = kmers_t(genomes, k)
         lab = torch.arange(genomes.shape[0], device=device, dtype=torch.int16)[:, None].expand_as(km).reshape(-1)
         km = km.reshape(-1)
@@ -99,6 +123,8 @@ def build_db(device, seed, k, htsize, n_targets, lam, genomes=None, shard=None):
                                app_r.data_ptr() if n_app else None, n_app,
                                d_sz.data_ptr(), C.byref(n_keys), stream))
     n = n_keys.value
+    if count_only:
+        return n
     d_keys = torch.empty(max(n, 1), dtype=torch.int32, device=device)
     d_labels = torch.empty(max(n, 1), dtype=torch.int16, device=device)
     d_off = torch.empty(nb, dtype=torch.int64, device=device)
