@@ -12,6 +12,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +89,11 @@ void index_abort(mc_ctx *c)
 {
     if (c->build.d_count) (void)hipFree(c->build.d_count);
     if (c->build.d_failed) (void)hipFree(c->build.d_failed);
+    if (c->build.d_blk) (void)hipFree(c->build.d_blk);
+    if (c->build.d_koff) (void)hipFree(c->build.d_koff);
+    if (c->build.d_st_sz) (void)hipFree(c->build.d_st_sz);
+    if (c->build.d_st_keys) (void)hipFree(c->build.d_st_keys);
+    if (c->build.d_st_labels) (void)hipFree(c->build.d_st_labels);
     c->build = mcint::IndexBuild();
 }
 
@@ -127,7 +136,8 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     c->info.part = part; c->info.n_parts = n_parts;
     const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
     if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess ||
-        hipMalloc(&c->build.d_count, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess) {
+        hipMalloc(&c->build.d_count, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess ||
+        hipMalloc(&c->build.d_failed, 4) != hipSuccess) {
         (void)hipGetLastError();
         free_db(c); index_abort(c);
         return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
@@ -135,11 +145,14 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     hipStream_t st = c->streams[0];
     HIPCHK(hipMemsetAsync(c->build.d_count, 0, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4, st));
     HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, st));
+    HIPCHK(hipMemsetAsync(c->build.d_failed, 0, 4, st));
     c->build.open = true; c->build.pass = 0; c->build.n_keys_total = n_keys_total;
     return MC_OK;
 }
 
-// one chunk, device arrays in the context's key width
+// One chunk, device arrays in the context's key width.  Nothing is allocated per call (the per-workgroup sums
+// and their offsets live in the build's grow-only scratch), nothing is copied to the host and nothing is waited
+// for: the launches are queued on the build stream and the caller may reuse its arrays once that stream passed.
 template <bool WIDE>
 int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels, uint64_t n_keys,
                     uint64_t b0, uint64_t b1)
@@ -148,34 +161,31 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
     const uint64_t nb = b1 - b0;
     hipStream_t st = c->streams[0];
     const uint32_t nblk = (uint32_t)((nb + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
-    Scope tmp;
-    uint32_t *d_bk = nullptr, *d_bo = nullptr;
-    TMP_MALLOC(tmp, d_bk, (size_t)nblk * 4);
-    TMP_MALLOC(tmp, d_bo, (size_t)nblk * 4);
-    hipLaunchKernelGGL(mc::block_sums_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz, nb, 255u, d_bk, d_bo);
+    mcint::IndexBuild &B = c->build;
+    if (nblk > B.blk_cap) {
+        HIPCHK(hipStreamSynchronize(st));                   // an earlier chunk may still read the old scratch
+        if (B.d_blk) (void)hipFree(B.d_blk);
+        if (B.d_koff) (void)hipFree(B.d_koff);
+        B.d_blk = nullptr; B.d_koff = nullptr; B.blk_cap = 0;
+        HIPCHK(hipMalloc(&B.d_blk, (size_t)nblk * 2 * 4));   // k-mers per workgroup | (unused) overflow sums
+        HIPCHK(hipMalloc(&B.d_koff, (size_t)nblk * 8));
+        B.blk_cap = nblk;
+    }
+    hipLaunchKernelGGL(mc::block_sums_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz, nb, 255u, B.d_blk, B.d_blk + nblk);
     HIPCHK(hipGetLastError());
-    std::vector<uint32_t> bk(nblk);
-    HIPCHK(hipMemcpyAsync(bk.data(), d_bk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint64_t> koff(nblk);
-    uint64_t ak = 0;
-    for (uint32_t i = 0; i < nblk; i++) { koff[i] = ak; ak += bk[i]; }
-    if (ak != n_keys) return fail(MC_EINVAL, "bucket sizes do not sum to n_keys");
-    uint64_t *d_koff = nullptr;
-    TMP_MALLOC(tmp, d_koff, (size_t)nblk * 8);
-    HIPCHK(hipMemcpyAsync(d_koff, koff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mc::mz::mz_scan_blocks_kernel, dim3(1), dim3(256), 0, st, B.d_blk, nblk, B.d_koff, n_keys, B.d_failed);
+    HIPCHK(hipGetLastError());
     if (c->build.pass == 0)
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
-                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, B.d_koff, c->k, c->mz_m,
                            c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr, (unsigned int *)nullptr);
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, B.d_failed);
     else
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
-                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, d_koff, c->k, c->mz_m,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, B.d_koff, c->k, c->mz_m,
                            c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
-                           c->d_mz_lines, c->d_mz_extra, c->build.d_failed);
+                           c->d_mz_lines, c->d_mz_extra, B.d_failed);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));       // the temporaries go out of scope
     c->build.fed[c->build.pass] += n_keys;
     c->build.bucket_lo = std::min(c->build.bucket_lo, b0);
     c->build.bucket_hi = std::max(c->build.bucket_hi, b1);
@@ -184,8 +194,9 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
 
 int convert_keys(mc_ctx *c, void *d_raw, int key_bytes, uint64_t n, bool raw_owned, void **out, bool *out_owned);
 
+// sync: return only when the build stream has passed (the caller may then reuse or free its arrays)
 int index_add_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int key_bytes, const uint16_t *d_labels,
-                     uint64_t n_keys, uint64_t b0, uint64_t b1)
+                     uint64_t n_keys, uint64_t b0, uint64_t b1, bool sync = false)
 {
     if (!c->build.open) return fail(MC_ESTATE, "mc_index_add before mc_index_begin");
     if (b0 >= b1 || b1 > c->htsize) return fail(MC_EINVAL, "bad bucket range of the chunk");
@@ -194,8 +205,31 @@ int index_add_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int key
     int rc = convert_keys(c, const_cast<void *>(d_keys), key_bytes, n_keys, false, &keys, &owned);
     if (rc) return rc;
     if (owned) tmp.add(keys);
-    return c->wide ? index_add_typed<true>(c, d_sz, keys, d_labels, n_keys, b0, b1)
-                   : index_add_typed<false>(c, d_sz, keys, d_labels, n_keys, b0, b1);
+    rc = c->wide ? index_add_typed<true>(c, d_sz, keys, d_labels, n_keys, b0, b1)
+                 : index_add_typed<false>(c, d_sz, keys, d_labels, n_keys, b0, b1);
+    if ((owned || sync) && rc == MC_OK) HIPCHK(hipStreamSynchronize(c->streams[0]));       // the widened copy goes out of scope
+    return rc;
+}
+
+// staging arrays of the build for a chunk of nb buckets / n_keys k-mers of key_bytes each (grow-only)
+int index_staging(mc_ctx *c, uint64_t nb, uint64_t n_keys, int key_bytes)
+{
+    mcint::IndexBuild &B = c->build;
+    (void)key_bytes;                                         // the key staging holds 8 bytes per k-mer: any width
+    if (nb > B.st_sz_cap || n_keys > B.st_key_cap) {
+        HIPCHK(hipStreamSynchronize(c->streams[0]));
+        if (B.d_st_sz) (void)hipFree(B.d_st_sz);
+        if (B.d_st_keys) (void)hipFree(B.d_st_keys);
+        if (B.d_st_labels) (void)hipFree(B.d_st_labels);
+        B.d_st_sz = nullptr; B.d_st_keys = nullptr; B.d_st_labels = nullptr;
+        const size_t cb = (size_t)std::max<uint64_t>(nb, B.st_sz_cap), ck = (size_t)std::max<uint64_t>(n_keys ? n_keys : 1, B.st_key_cap);
+        B.st_sz_cap = 0; B.st_key_cap = 0;
+        HIPCHK(hipMalloc(&B.d_st_sz, cb));
+        HIPCHK(hipMalloc(&B.d_st_keys, ck * 8));
+        HIPCHK(hipMalloc(&B.d_st_labels, ck * 2));
+        B.st_sz_cap = cb; B.st_key_cap = ck;
+    }
+    return MC_OK;
 }
 
 int index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,
@@ -204,17 +238,21 @@ int index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes
     if (!c->build.open) return fail(MC_ESTATE, "mc_index_add before mc_index_begin");
     if (b0 >= b1 || b1 > c->htsize) return fail(MC_EINVAL, "bad bucket range of the chunk");
     const uint64_t nb = b1 - b0;
-    Scope tmp;
-    uint8_t *d_sz = nullptr; void *d_raw = nullptr; uint16_t *d_labels = nullptr;
-    TMP_MALLOC(tmp, d_sz, nb);
-    TMP_MALLOC(tmp, d_raw, (n_keys ? n_keys : 1) * (size_t)key_bytes);
-    TMP_MALLOC(tmp, d_labels, (n_keys ? n_keys : 1) * 2);
-    HIPCHK(hipMemcpy(d_sz, sz, nb, hipMemcpyHostToDevice));
+    int rc = index_staging(c, nb, n_keys, key_bytes);
+    if (rc) return rc;
+    mcint::IndexBuild &B = c->build;
+    hipStream_t st = c->streams[0];
+    // queued behind the kernels of the chunk before (same stream): the staging arrays are free by then
+    HIPCHK(hipMemcpyAsync(B.d_st_sz, sz, nb, hipMemcpyHostToDevice, st));
     if (n_keys) {
-        HIPCHK(hipMemcpy(d_raw, keys, n_keys * (size_t)key_bytes, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_labels, labels, n_keys * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(B.d_st_keys, keys, n_keys * (size_t)key_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(B.d_st_labels, labels, n_keys * 2, hipMemcpyHostToDevice, st));
     }
-    return index_add_device(c, d_sz, d_raw, key_bytes, d_labels, n_keys, b0, b1);
+    rc = index_add_device(c, B.d_st_sz, B.d_st_keys, key_bytes, B.d_st_labels, n_keys, b0, b1);
+    // the caller's host arrays are its own again when this returns (pageable memory is staged by the runtime before
+    // the copy call returns; pinned memory is read by the DMA engine later)
+    if (rc == MC_OK) HIPCHK(hipStreamSynchronize(st));
+    return rc;
 }
 
 // between the passes: sizes known -> headers, extra lines
@@ -234,9 +272,12 @@ int index_next_pass(mc_ctx *c)
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> blk(nblk);
     unsigned long long tot[4];
+    unsigned int failed0 = 0;
     HIPCHK(hipMemcpyAsync(blk.data(), d_blk, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&failed0, c->build.d_failed, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (failed0 & 4u) { free_db(c); index_abort(c); return fail(MC_EINVAL, "bucket sizes do not sum to n_keys"); }
     std::vector<uint64_t> boff(nblk);
     uint64_t acc = 0;
     for (uint32_t i = 0; i < nblk; i++) { boff[i] = acc; acc += blk[i]; }
@@ -244,13 +285,12 @@ int index_next_pass(mc_ctx *c)
     c->build.n_extra = acc; c->build.n_spilled = tot[0]; c->build.n_over = tot[1]; c->build.longest = (uint32_t)tot[2];
     c->build.n_crowded = tot[3];
     const size_t ebytes = (size_t)(acc ? acc : 1) * mc::mz::MZ_LINE;
-    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess || hipMalloc(&c->build.d_failed, 4) != hipSuccess) {
+    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess) {
         (void)hipGetLastError();
         free_db(c); index_abort(c);
         return fail(MC_ENOMEM, "minimizer index: not enough HBM for the extra lines");
     }
     HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
-    HIPCHK(hipMemsetAsync(c->build.d_failed, 0, 4, st));
     HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_boff, c->d_mz_lines);
     HIPCHK(hipGetLastError());
@@ -286,7 +326,8 @@ int index_end(mc_ctx *c)
     HIPCHK(hipStreamSynchronize(st));
     if (failed) {
         free_db(c); index_abort(c);
-        return fail(MC_EINVAL, (failed & 2u) ? "minimizer index: the second pass held k-mers the first did not (a line outgrew the chain sized for it)"
+        return fail(MC_EINVAL, (failed & 4u) ? "bucket sizes do not sum to n_keys" :
+                               (failed & 2u) ? "minimizer index: the second pass held k-mers the first did not (a line outgrew the chain sized for it)"
                                              : "minimizer index: a chain of a crowded line overflowed twice");
     }
     mc_db_info &I = c->info;
@@ -673,6 +714,66 @@ int DbFileStream::pass(const ChunkFn &f)
     return MC_OK;
 }
 
+void DbFileStream::plan()
+{
+    const uint64_t CH = 1ull << 24;   // buckets per chunk
+    const std::vector<uint8_t> &file_sz = fsz.empty() ? sz : fsz;
+    chunks.clear(); max_nfile = 0; max_nb = 0;
+    uint64_t fpos = file_k0;
+    for (uint64_t b0 = sb; b0 < se; b0 += CH) {
+        const uint64_t b1 = std::min(se, b0 + CH);
+        uint64_t nfile = 0;
+        for (uint64_t i = b0; i < b1; i++) nfile += file_sz[i];
+        chunks.push_back(Chunk{b0, b1, fpos, nfile});
+        max_nfile = std::max(max_nfile, nfile); max_nb = std::max(max_nb, b1 - b0);
+        fpos += nfile;
+    }
+}
+
+int DbFileStream::read(size_t i, uint8_t *sz_out, void *keys_out, uint16_t *labels_out, uint64_t *n_kept, int threads)
+{
+    const Chunk &C = chunks[i];
+    memcpy(sz_out, sz.data() + C.b0, C.b1 - C.b0);
+    // byte ranges of the two files, cut into slices of <= 32 MB, dealt to the threads
+    struct Slice { int fd; char *dst; size_t n; uint64_t off; };
+    std::vector<Slice> sl;
+    const size_t SL = 32u << 20;
+    auto cut = [&](int fd, void *dst, size_t bytes, uint64_t off) {
+        for (size_t at = 0; at < bytes; at += SL) sl.push_back(Slice{fd, (char *)dst + at, std::min(SL, bytes - at), off + at});
+    };
+    cut(fk, keys_out, C.nfile * (size_t)key_bytes, C.fpos * (uint64_t)key_bytes);
+    cut(fl, labels_out, C.nfile * 2, C.fpos * 2);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&]() {
+        for (size_t j; (j = next.fetch_add(1)) < sl.size();)
+            if (!pread_all(sl[j].fd, sl[j].dst, sl[j].n, sl[j].off)) bad = true;
+    };
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, sl.size()));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) return fail(MC_EIO, base + ".ky/.lb shorter than the bucket sizes say");
+    uint64_t nkeep = C.nfile;
+    if (!fsz.empty()) {                      // drop the unsampled buckets
+        uint64_t r = 0, w = 0;
+        char *kb = (char *)keys_out; char *lb = (char *)labels_out;
+        for (uint64_t b = C.b0; b < C.b1; b++) {
+            const uint64_t n = fsz[b];
+            if (n && sz[b]) {
+                memmove(kb + w * key_bytes, kb + r * key_bytes, n * key_bytes);
+                memmove(lb + w * 2, lb + r * 2, n * 2);
+                w += n;
+            }
+            r += n;
+        }
+        nkeep = w;
+    }
+    *n_kept = nkeep;
+    return MC_OK;
+}
+
 // primary lines of one part (every part has the same number); 0 = more than the 32-bit line index of a context holds
 uint64_t lines_per_part(uint64_t n_keys_total, uint32_t n_parts, double fill)
 {
@@ -714,10 +815,17 @@ uint32_t min_parts(uint64_t n_keys_total, uint32_t max_parts, uint64_t free_byte
 
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode == 1 && mz_eligible(c, n_keys_total); }
 
-int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts)
+// The files -> the index of every member, as a pipeline.  A reader thread fills one of two pinned chunk buffers
+// (parallel preads) while the other is in flight; each chunk is uploaded ONCE per device on that device's copy stream
+// into one of two staging sets -- members that share a device share the upload -- and every member queues its build
+// kernels behind the upload on its own stream: no allocation, no host round trip and no synchronisation per chunk
+// and member (round 2 did all three, member after member: an N-member group loaded in 2 N sequential passes).
+int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts, uint32_t part0, double fill)
 {
     int rc = MC_OK;
-    if (!getenv("MC_MZ_FILL")) {
+    if (fill > 0.0) {
+        for (uint32_t i = 0; i < n; i++) ctxs[i]->fill_hint = fill;
+    } else if (!getenv("MC_MZ_FILL")) {
         // one fill for all members: what the member with the least free HBM can afford
         uint64_t free_min = ~0ull;
         for (uint32_t i = 0; i < n; i++) {
@@ -734,22 +842,135 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
     auto abort_all = [&]() { const std::string keep = g_err; for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); free_db(ctxs[i]); index_abort(ctxs[i]); } g_err = keep; };
     for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
         rc = set_dev(ctxs[i]);
-        if (rc == MC_OK) rc = index_begin(ctxs[i], F.n_keys_kept, i % n_parts, n_parts);
+        if (rc == MC_OK) rc = index_begin(ctxs[i], F.n_keys_kept, (part0 + i) % n_parts, n_parts);
     }
-    for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
-        rc = F.pass([&](const uint8_t *sz, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t b0, uint64_t b1) {
-            for (uint32_t i = 0; i < n; i++) {
-                int r = set_dev(ctxs[i]);
-                if (r == MC_OK) r = index_add_host(ctxs[i], sz, keys, F.key_bytes, labels, nk, b0, b1);
-                if (r != MC_OK) return r;
+    if (rc != MC_OK) { abort_all(); return rc; }
+
+    F.plan();
+    const size_t kb = (size_t)F.key_bytes;
+    const size_t cap_k = (size_t)std::max<uint64_t>(F.max_nfile, 1), cap_b = (size_t)std::max<uint64_t>(F.max_nb, 1);
+    // per distinct device: copy stream, two staging sets, "copied" events; per member: "built" events
+    struct Dev { int device; hipStream_t cs = nullptr; uint8_t *d_sz[2] = {nullptr, nullptr}; char *d_keys[2] = {nullptr, nullptr};
+                 uint16_t *d_labels[2] = {nullptr, nullptr}; hipEvent_t copied[2] = {nullptr, nullptr}; };
+    std::vector<Dev> devs;
+    std::vector<int> dev_of(n);
+    std::vector<hipEvent_t> built((size_t)n * 2, nullptr);
+    uint8_t *h_buf[2] = {nullptr, nullptr};
+    const size_t h_bytes = ((cap_b + 255) & ~(size_t)255) + cap_k * kb + cap_k * 2 + 256;
+    auto h_sz = [&](int s) { return h_buf[s]; };
+    auto h_keys = [&](int s) { return (void *)(h_buf[s] + ((cap_b + 255) & ~(size_t)255)); };
+    auto h_labels = [&](int s) { return (uint16_t *)(h_buf[s] + ((cap_b + 255) & ~(size_t)255) + ((cap_k * kb + 1) & ~(size_t)1)); };
+    auto cleanup = [&]() {
+        for (auto &D : devs) {
+            (void)hipSetDevice(D.device);
+            (void)hipDeviceSynchronize();
+            for (int s2 = 0; s2 < 2; s2++) {
+                if (D.d_sz[s2]) (void)hipFree(D.d_sz[s2]);
+                if (D.d_keys[s2]) (void)hipFree(D.d_keys[s2]);
+                if (D.d_labels[s2]) (void)hipFree(D.d_labels[s2]);
+                if (D.copied[s2]) (void)hipEventDestroy(D.copied[s2]);
             }
-            return (int)MC_OK;
+            if (D.cs) (void)hipStreamDestroy(D.cs);
+        }
+        for (uint32_t i = 0; i < n; i++)
+            for (int s2 = 0; s2 < 2; s2++)
+                if (built[(size_t)i * 2 + s2]) { (void)hipSetDevice(ctxs[i]->device); (void)hipEventDestroy(built[(size_t)i * 2 + s2]); }
+        for (int s2 = 0; s2 < 2; s2++) if (h_buf[s2]) (void)hipHostFree(h_buf[s2]);
+    };
+    auto setup = [&]() -> int {
+        for (uint32_t i = 0; i < n; i++) {
+            int at = -1;
+            for (size_t d = 0; d < devs.size(); d++) if (devs[d].device == ctxs[i]->device) at = (int)d;
+            if (at < 0) { Dev D; D.device = ctxs[i]->device; devs.push_back(D); at = (int)devs.size() - 1; }
+            dev_of[i] = at;
+        }
+        for (auto &D : devs) {
+            HIPCHK(hipSetDevice(D.device));
+            HIPCHK(hipStreamCreateWithFlags(&D.cs, hipStreamNonBlocking));
+            for (int s2 = 0; s2 < 2; s2++) {
+                HIPCHK(hipMalloc(&D.d_sz[s2], cap_b));
+                HIPCHK(hipMalloc(&D.d_keys[s2], cap_k * kb));
+                HIPCHK(hipMalloc(&D.d_labels[s2], cap_k * 2));
+                HIPCHK(hipEventCreateWithFlags(&D.copied[s2], hipEventDisableTiming));
+            }
+        }
+        for (uint32_t i = 0; i < n; i++) {
+            HIPCHK(hipSetDevice(ctxs[i]->device));
+            for (int s2 = 0; s2 < 2; s2++) HIPCHK(hipEventCreateWithFlags(&built[(size_t)i * 2 + s2], hipEventDisableTiming));
+        }
+        for (int s2 = 0; s2 < 2; s2++) HIPCHK(hipHostMalloc((void **)&h_buf[s2], h_bytes, hipHostMallocPortable));
+        return MC_OK;
+    };
+    rc = setup();
+    int n_threads = 8;
+    if (const char *e = getenv("MC_LOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_threads = v; }
+
+    for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
+        // reader: chunk i into host buffer i % 2
+        std::mutex mu;
+        std::condition_variable cv;
+        bool is_free[2] = {true, true}, is_ready[2] = {false, false};
+        uint64_t nk[2] = {0, 0};
+        int reader_rc = MC_OK;
+        std::string reader_err;
+        bool stop = false;
+        std::thread reader([&]() {
+            for (size_t i = 0; i < F.chunks.size(); i++) {
+                const int s2 = (int)(i & 1);
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return is_free[s2] || stop; }); if (stop) return; is_free[s2] = false; }
+                uint64_t kept = 0;
+                const int r = F.read(i, h_sz(s2), h_keys(s2), h_labels(s2), &kept, n_threads);
+                { std::lock_guard<std::mutex> lk(mu); nk[s2] = kept; is_ready[s2] = true; if (r != MC_OK) { reader_rc = r; reader_err = g_err; } }
+                cv.notify_all();
+                if (r != MC_OK) return;
+            }
         });
+        for (size_t i = 0; i < F.chunks.size() && rc == MC_OK; i++) {
+            const int s2 = (int)(i & 1);
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return is_ready[s2]; }); is_ready[s2] = false; if (reader_rc != MC_OK) { rc = reader_rc; g_err = reader_err; } }
+            if (rc != MC_OK) break;
+            const DbFileStream::Chunk &C = F.chunks[i];
+            const uint64_t k_n = nk[s2];
+            auto enqueue = [&]() -> int {
+                for (size_t d = 0; d < devs.size(); d++) {
+                    Dev &D = devs[d];
+                    HIPCHK(hipSetDevice(D.device));
+                    for (uint32_t m = 0; m < n; m++)          // the staging set was read by the kernels of chunk i - 2
+                        if (dev_of[m] == (int)d && i >= 2) HIPCHK(hipStreamWaitEvent(D.cs, built[(size_t)m * 2 + s2], 0));
+                    HIPCHK(hipMemcpyAsync(D.d_sz[s2], h_sz(s2), C.b1 - C.b0, hipMemcpyHostToDevice, D.cs));
+                    if (k_n) {
+                        HIPCHK(hipMemcpyAsync(D.d_keys[s2], h_keys(s2), k_n * kb, hipMemcpyHostToDevice, D.cs));
+                        HIPCHK(hipMemcpyAsync(D.d_labels[s2], h_labels(s2), k_n * 2, hipMemcpyHostToDevice, D.cs));
+                    }
+                    HIPCHK(hipEventRecord(D.copied[s2], D.cs));
+                }
+                for (uint32_t m = 0; m < n; m++) {
+                    Dev &D = devs[dev_of[m]];
+                    int r = set_dev(ctxs[m]);
+                    if (r != MC_OK) return r;
+                    HIPCHK(hipStreamWaitEvent(ctxs[m]->streams[0], D.copied[s2], 0));
+                    r = index_add_device(ctxs[m], D.d_sz[s2], D.d_keys[s2], F.key_bytes, D.d_labels[s2], k_n, C.b0, C.b1);
+                    if (r != MC_OK) return r;
+                    HIPCHK(hipEventRecord(built[(size_t)m * 2 + s2], ctxs[m]->streams[0]));
+                }
+                for (auto &D : devs) { HIPCHK(hipSetDevice(D.device)); HIPCHK(hipEventSynchronize(D.copied[s2])); }    // the host buffer is free again
+                return MC_OK;
+            };
+            rc = enqueue();
+            { std::lock_guard<std::mutex> lk(mu); is_free[s2] = true; }
+            cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        reader.join();
         for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
             rc = set_dev(ctxs[i]);
             if (rc == MC_OK) rc = pass == 0 ? index_next_pass(ctxs[i]) : index_end(ctxs[i]);
         }
     }
+    const std::string keep = g_err;
+    cleanup();
+    g_err = keep;
     if (rc != MC_OK) abort_all();
     return rc;
 }
@@ -895,7 +1116,7 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
     bool fallback = false;
     if (mcint::minimizer_index_possible(c, F.n_keys_kept)) {
         // two passes over the files in chunks: neither the raw arrays nor a second copy ever sits in HBM
-        rc = mcint::load_streamed(&c, 1, F, 1);
+        rc = mcint::load_streamed(&c, 1, F, 1, 0, 0.0);
         if (rc != MC_ENOMEM) return rc;
         fprintf(stderr, "libmcclark: %s; falling back to the bucket-line table\n", g_err.c_str());
         fallback = true;
@@ -936,15 +1157,11 @@ int mc_load_db_part(mc_ctx *c, const char *base, int key_bytes, uint32_t samplin
     mcint::DbFileStream F;
     rc = F.open(base, key_bytes, sampling, c->htsize, 0, c->htsize); if (rc) return rc;
     if (!mz_eligible(c, F.n_keys_kept)) return fail(MC_EINVAL, "line-range parts need the minimizer index (k >= 16)");
-    rc = index_begin(c, F.n_keys_kept, part, n_parts);
-    for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
-        rc = F.pass([&](const uint8_t *sz, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t b0, uint64_t b1) {
-            return index_add_host(c, sz, keys, key_bytes, labels, nk, b0, b1);
-        });
-        if (rc == MC_OK) rc = pass == 0 ? index_next_pass(c) : index_end(c);
-    }
-    if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; }
-    return rc;
+    // the parts of a table are loaded by different processes and must agree on the fill: a function of the table, the
+    // part count and the card's TOTAL memory (index_begin), not of what happens to be free here
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    return mcint::load_streamed(&c, 1, F, n_parts, part, mcint::choose_fill(F.n_keys_kept, n_parts, (uint64_t)tot));
 }
 
 /* ---- the streamed index build, for callers that produce the table in chunks ---- */
@@ -961,7 +1178,7 @@ int mc_index_add_device(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, int 
     if (!c || !d_sz) return fail(MC_EINVAL, "NULL argument");
     if (key_bytes != 2 && key_bytes != 4 && key_bytes != 8) return fail(MC_EINVAL, "key_bytes must be 2, 4 or 8");
     int rc = set_dev(c); if (rc) return rc;
-    return index_add_device(c, d_sz, d_keys, key_bytes, d_labels, n_keys, bucket_begin, bucket_end);
+    return index_add_device(c, d_sz, d_keys, key_bytes, d_labels, n_keys, bucket_begin, bucket_end, true);
 }
 
 int mc_index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes, const uint16_t *labels,

@@ -243,7 +243,7 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
         const uint32_t G = mode == MC_GROUP_SHARDS ? n / S : 1, n_act = mode == MC_GROUP_SHARDS ? S * G : n;
         shard_kind = 0;
         if (mode == MC_GROUP_REPLICAS) {
-            if (mz) rc = mcint::load_streamed(g->ctx.data(), n, F, 1);
+            if (mz) rc = mcint::load_streamed(g->ctx.data(), n, F, 1, 0, 0.0);
             if (!mz || (rc == MC_ENOMEM && !want_auto)) {
                 for (uint32_t m = 0; m < n; m++) {           // bucket-line tables (or the fallback to them), device by device
                     rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, 0, 0);
@@ -252,7 +252,7 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
             }
         } else if (by_lines) {
             shard_kind = 1;
-            rc = mcint::load_streamed(g->ctx.data(), n_act, F, S);
+            rc = mcint::load_streamed(g->ctx.data(), n_act, F, S, 0, 0.0);
         } else {
             shard_kind = 2;                                   // the reference's own partition (CuClarkDB.cu:552-559)
             for (uint32_t m = 0; m < n; m++) {

@@ -64,7 +64,12 @@ struct IndexBuild {
     uint64_t fed[2] = {0, 0};          // k-mers fed in each pass
     uint64_t bucket_lo = ~0ull, bucket_hi = 0;
     uint32_t *d_count = nullptr;       // per owned line: k-mers (pass 0), cursor (pass 1)
-    unsigned int *d_failed = nullptr;  // set by the placing pass when a k-mer found no slot
+    unsigned int *d_failed = nullptr;  // bit 0: a k-mer found no slot; bit 1: the second pass outgrew a chain; bit 2: a chunk's
+                                       // bucket sizes do not add up to its k-mers
+    // scratch that lives as long as the build (grow-only): feeding a chunk allocates nothing and waits for nothing
+    uint32_t *d_blk = nullptr; uint64_t *d_koff = nullptr; size_t blk_cap = 0;
+    uint8_t *d_st_sz = nullptr; void *d_st_keys = nullptr; uint16_t *d_st_labels = nullptr;   // staging of mc_index_add_host
+    size_t st_sz_cap = 0, st_key_cap = 0;                                                     // buckets / k-mers
     uint64_t n_extra = 0, n_spilled = 0, n_over = 0, n_crowded = 0;
     uint32_t longest = 0;
 };
@@ -149,13 +154,24 @@ struct DbFileStream {
     // one pass over the chunks; f(sz of [b0,b1), keys, labels, n_keys, b0, b1) returns MC_OK to continue
     typedef std::function<int(const uint8_t *, const void *, const uint16_t *, uint64_t, uint64_t, uint64_t)> ChunkFn;
     int pass(const ChunkFn &f);
+    // The same chunks, addressable: plan() lists them once (bucket range, file position, k-mers in the files);
+    // read(i, ...) fills caller-provided (pinned) arrays with chunk i -- the .ky/.lb byte ranges are cut into slices
+    // read by several threads at once (one thread copies from the page cache at 2-3 GB/s; the files of a full
+    // table are 40 GB, twice) -- and returns the k-mers kept after sampling.
+    struct Chunk { uint64_t b0, b1, fpos, nfile; };
+    std::vector<Chunk> chunks;
+    uint64_t max_nfile = 0, max_nb = 0;
+    void plan();
+    int read(size_t i, uint8_t *sz_out, void *keys_out, uint16_t *labels_out, uint64_t *n_kept, int threads);
 };
 
 // Build the minimizer index of every context from one stream of the files (each chunk is read once per
 // pass and fed to all contexts).  Context i builds part i % n_parts of n_parts (n_parts = 1: every context
 // builds the whole [sb, se) range -- replicas; n > n_parts: several groups that each hold the whole table).
 // MC_ENOMEM when a context cannot hold its lines.
-int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts);
+// Context i builds part (part0 + i) % n_parts.  fill > 0 fixes the k-mers per line (otherwise: what the member with
+// the least free HBM affords).
+int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts, uint32_t part0 = 0, double fill = 0.0);
 bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total);
 // The arithmetic of the index plan (no device needed: mc_index_plan exposes it to tests).
 // lines_per_part: primary lines of ONE part at `fill` k-mers per line; 0 when that exceeds the 32-bit line index.

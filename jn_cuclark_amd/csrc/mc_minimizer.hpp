@@ -307,6 +307,25 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
     }
 }
 
+// exclusive offsets (u64) of the per-workgroup k-mer counts of a chunk, on the device (one workgroup: a chunk has
+// 16 K workgroups of buckets, the whole table 1.6 M), so that feeding a chunk needs no round trip to the host;
+// a chunk whose bucket sizes do not add up to the k-mers the caller announced sets bit 2 of `failed`
+static __global__ __launch_bounds__(256)
+void mz_scan_blocks_kernel(const uint32_t *blk, uint32_t n, uint64_t *off, uint64_t expect, unsigned int *failed)
+{
+    __shared__ uint64_t s_sum[256];
+    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += blk[i];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    uint64_t pre = 0, tot = 0;
+    for (uint32_t t = 0; t < 256u; t++) { if (t < threadIdx.x) pre += s_sum[t]; tot += s_sum[t]; }
+    for (uint32_t i = lo; i < hi; i++) { off[i] = pre; pre += blk[i]; }
+    if (threadIdx.x == 0 && tot != expect) atomicOr(failed, 4u);
+}
+
 // after PASS 0: extra lines of a line with `c` k-mers (crowded: 2^s chains of MZ_EMAX lines + one spare)
 __host__ __device__ __forceinline__ uint32_t chain_len_of(uint32_t c)
 {

@@ -284,3 +284,67 @@ def build_genome_db(genomes, k, htsize, n_ranges=16, slab=256):
         total += int(lab.numel())
         del comp, sz, lab
     return chunks, total
+
+
+# --------------------------------------------------------------------------------------------------
+# files: the generated table as <base>.sz/.ky/.lb, reads as FASTQ text (tools/file_e2e.py, tests/test_gpu_filesize.py)
+# --------------------------------------------------------------------------------------------------
+def write_db_files(base, chunks):
+    """Append bucket-order chunks (d_sz, d_keys int32, d_labels int16, b0, b1) -- consecutive ranges that cover the
+    table -- to <base>.sz/.ky/.lb: the reference's on-disk format (src/hashTable_hh.hh:473-546: one size byte per
+    bucket, 4-byte quotients, 2-byte labels, bucket order).  Returns (n_keys, bytes written)."""
+    n_keys = total = 0
+    with open(base + ".sz", "wb") as fs, open(base + ".ky", "wb") as fk, open(base + ".lb", "wb") as fl:
+        for d_sz, d_keys, d_labels, _b0, _b1 in chunks:
+            for f, t in ((fs, d_sz), (fk, d_keys), (fl, d_labels)):
+                a = t.cpu().numpy()
+                a.tofile(f)
+                total += a.nbytes
+            n_keys += int(d_keys.numel())
+    return n_keys, total
+
+
+FASTQ_RECORD = 2 + 10 + 1 + 150 + 3 + 150 + 1          # "@r" + 10 digits, 150 bases, "+", 150 qualities
+
+
+def write_fastq(path, genomes, n_reads, seed, planted_frac=0.5, sub_rate=0.01, slab=2_000_000):
+    """n_reads x 150 bp as FASTQ text (317 bytes per record, names @r0000000000 ...), the mix of make_reads: the
+    first planted_frac are windows of the genomes with substitutions, the rest uniform random.  Generated slab by
+    slab on the GPU, written as it goes.  Returns the source genome of every planted read (int64 tensor, host)."""
+    dev = genomes.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    T, G = genomes.shape
+    L = 150
+    flat = genomes.reshape(-1)
+    n_planted = int(n_reads * planted_frac)
+    ar = torch.arange(L, device=dev, dtype=torch.int64)[None, :]
+    base_of = torch.tensor([ord(c) for c in "TGCA"], dtype=torch.uint8, device=dev)      # codes A=3 C=2 G=1 T=0
+    pow10 = torch.tensor([10 ** (9 - j) for j in range(10)], dtype=torch.int64, device=dev)[None, :]
+    truth = []
+    with open(path, "wb") as f:
+        for s in range(0, n_reads, slab):
+            e = min(n_reads, s + slab)
+            m = e - s
+            n_pl = max(0, min(e, n_planted) - s)
+            codes = torch.randint(0, 4, (m, L), dtype=torch.uint8, device=dev, generator=g)
+            if n_pl:
+                gi = torch.randint(0, T, (n_pl,), device=dev, generator=g)
+                truth.append(gi.cpu())
+                pos = torch.randint(0, G - L + 1, (n_pl,), device=dev, generator=g)
+                win = flat[(gi * G + pos)[:, None] + ar]
+                mut = torch.rand((n_pl, L), device=dev, generator=g) < sub_rate
+                delta = torch.randint(1, 4, (n_pl, L), dtype=torch.uint8, device=dev, generator=g)
+                codes[:n_pl] = torch.where(mut, (win + delta) & 3, win)
+            rec = torch.empty((m, FASTQ_RECORD), dtype=torch.uint8, device=dev)
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            idx = torch.arange(s, e, device=dev, dtype=torch.int64)[:, None]
+            rec[:, 2:12] = ((idx // pow10) % 10 + 48).to(torch.uint8)
+            rec[:, 12] = 10
+            rec[:, 13:163] = base_of[codes.to(torch.int64)]
+            rec[:, 163] = 10; rec[:, 164] = ord("+"); rec[:, 165] = 10
+            rec[:, 166:316] = ord("I")
+            rec[:, 316] = 10
+            rec.cpu().numpy().tofile(f)
+            del rec, codes
+    return torch.cat(truth) if truth else torch.zeros(0, dtype=torch.int64)

@@ -139,7 +139,25 @@ orc_db *orc_db_load(const char *base, uint64_t htsize, int key_bytes, uint32_t s
             if (keep[b]) n_keep += sz[b];
         }
     }
-    {
+    if (all) {
+        /* every bucket is kept: the two arrays are the files as they are (one read each, no second copy -- a
+         * full-size table is 39 GB of them: tests/test_gpu_filesize.py) */
+        db = (orc_db *)calloc(1, sizeof(orc_db));
+        if (db) {
+            db->htsize = htsize; db->key_bytes = key_bytes; db->n = n_file;
+            db->off = (uint64_t *)malloc((htsize + 1) * sizeof(uint64_t));
+            db->keys = malloc(n_file ? n_file * (size_t)key_bytes : 1);
+            db->labels = (uint16_t *)malloc(n_file ? n_file * sizeof(uint16_t) : 1);
+            int ok = db->off && db->keys && db->labels;
+            if (ok) {
+                uint64_t acc = 0;       /* ref: CuClarkDB.cu:589-617 -- exclusive prefix sums of the bucket sizes */
+                for (uint64_t b = 0; b < htsize; b++) { db->off[b] = acc; acc += sz[b]; }
+                db->off[htsize] = acc;
+                ok = fread(db->keys, (size_t)key_bytes, n_file, fk) == n_file && fread(db->labels, 2, n_file, fl) == n_file;
+            }
+            if (!ok) { orc_db_free(db); db = NULL; }
+        }
+    } else {
         void *keys = malloc(n_keep ? n_keep * (size_t)key_bytes : 1);
         uint16_t *labels = (uint16_t *)malloc(n_keep ? n_keep * 2 : 1);
         uint8_t *sz_kept = (uint8_t *)malloc(htsize);

@@ -1,0 +1,204 @@
+"""The file loader and the host driver at the metric's size (run on the GPU box):
+  1. the bench's 6.45e9-k-mer table (HTSIZE 1610612741, k = 31, 4096 targets) written as .sz/.ky/.lb -- the
+     reference's on-disk format, 41 GB -- to a directory with room for it (/dev/shm, $TMPDIR, /tmp);
+  2. mc_load_db of those files, timed (what a `kent -c` user waits for; reference: CuClarkDB::read,
+     src/CuClarkDB.cu:463-770, its timer -DTIME_DBLOADING at src/CuCLARK_hh.hh:617-628), mc_db_info compared with the
+     chunk-fed build of the same table, and the classification of 1 M reads compared between the two (bit-identical)
+     and with the ground truth (a read sampled from genome g is assigned to target g);
+  3. a FASTQ file of N reads (default 40 M x 150 bp, 12.7 GB), `bin/cuCLARK -k 31 -O reads.fq` against that
+     database, twice: the program's own "Done in Xs (N reads/min, M reads)" (the reference's timer,
+     src/CuCLARK_hh.hh:552-563, :1931-1939: file -> CSV, the database load is outside it) and the wall clock of the
+     whole process; the CSV is checked against the ground truth.
+    python tools/file_e2e.py [--reads N] [--threads 16] [--dir D] [--json out.json]
+The oracle comparison of the file-loaded table lives in tests/test_gpu_filesize.py (tools do not touch oracle/)."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np
+import torch
+from jn_cuclark_amd import CuClarkDB, synth_gpu
+
+K, HT, T, LAM, GLEN, MAXHITS = 31, 1610612741, 4096, 3.75, 100_000, 15
+
+
+def pick_dir(need_bytes, want=None):
+    for d in ([want] if want else []) + ["/dev/shm", os.environ.get("TMPDIR") or "/tmp", "/tmp", ROOT]:
+        try:
+            if d and os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes + (8 << 30):
+                return d
+        except OSError:
+            pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=40_000_000)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--batches", type=int, default=32)
+    ap.add_argument("--dir", default=None)
+    ap.add_argument("--lam", type=float, default=LAM)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--skip-load-compare", action="store_true")
+    ap.add_argument("--load-times", action="store_true",
+                    help="also time tools/load_time.py on the files: 1 member, 2 and 3 members (parts) on this card, with this "
+                         "build and -- when build/libmcclark_r02.so is there -- with round 2's loader")
+    a = ap.parse_args()
+    out = {}
+    dev = torch.device("cuda", 0)
+    need = int(6.5e9 * 6.3 * max(a.lam, 0.1) / 3.75 + 3e9) + HT + a.reads * (synth_gpu.FASTQ_RECORD + 40)
+    d = pick_dir(need, a.dir)
+    if d is None:
+        print("no directory with %.0f GB free: nothing measured" % (need / 1e9))
+        return 2
+    work = os.path.join(d, "mc_file_e2e_%d" % os.getpid())
+    os.makedirs(work, exist_ok=True)
+    try:
+        return run(a, out, dev, work)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def run(a, out, dev, work):
+    base = os.path.join(work, "db_central_k%d_t%d_s%d_m0.tsk" % (K, T, HT))
+    genomes = synth_gpu.make_genomes(T, GLEN, seed=31, device=dev)
+    n_ranges = 16
+    ranges = [(HT * j // n_ranges, HT * (j + 1) // n_ranges) for j in range(n_ranges)]
+
+    def chunks():
+        for b0, b1 in ranges:
+            d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, K, HT, T, a.lam, genomes=genomes, shard=(b0, b1))
+            yield d_sz, d_keys, d_labels, b0, b1
+            del d_sz, d_keys, d_labels
+
+    t0 = time.time()
+    n_keys, nbytes = synth_gpu.write_db_files(base, chunks())
+    out["db_files"] = {"dir": os.path.dirname(work), "n_kmers": n_keys, "bytes": nbytes, "write_s": round(time.time() - t0, 1)}
+    print("database files: %.2fe9 k-mers, %.1f GB in %s, generated + written in %.1f s" % (n_keys / 1e9, nbytes / 1e9, work, time.time() - t0), flush=True)
+    torch.cuda.empty_cache()
+
+    n1 = 1_000_000
+    rp, con, truth = synth_gpu.make_reads(genomes, n1, 150, seed=77, return_truth=True)
+    st = torch.cuda.current_stream().cuda_stream
+    # ---- 2. load from the files --------------------------------------------------------------------------------
+    loads = []
+    fin_file = info_file = None
+    for rep in range(2):                     # second time: the files come from the page cache
+        with CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=MAXHITS) as db:
+            t0 = time.time()
+            assert db.read(base) is True
+            loads.append(round(time.time() - t0, 2))
+            info_file = db.db_info()
+            fin_file = torch.zeros((n1, 5), dtype=torch.int16, device=dev)
+            db.query_device(rp, con, final_t=fin_file, stream=st)
+            torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    out["load"] = {"seconds": loads, "GB_per_s": [round(2 * (nbytes - HT) / 1e9 / s, 2) for s in loads],
+                   "what": "mc_load_db of the .sz/.ky/.lb files: .sz once, .ky/.lb streamed twice (count pass, place pass) "
+                           "through two pinned chunk buffers into the index build; first = as written, second = again"}
+    print("mc_load_db: %s s (%.1f GB of index, %.2f k-mers per line)" % (loads, info_file["device_bytes"] / 1e9,
+                                                                          n_keys / max(1, info_file["n_lines"])), flush=True)
+    fin = fin_file.cpu().numpy().view(np.uint16)
+    tr = truth.cpu().numpy()
+    ok = fin[: tr.size, 1] == tr + 1
+    assert ok.mean() > 0.995 and int(fin[tr.size:, 0].astype(np.int64).sum()) < 100
+    out["load"]["ground_truth_ok"] = round(float(ok.mean()), 5)
+    if not a.skip_load_compare:
+        with CuClarkDB(k=K, numBatches=1, numTargets=T, device=0, htsize=HT, maxhits=MAXHITS) as db:
+            t0 = time.time()
+            db.read_chunks(chunks, n_keys, device=True)
+            fed_s = time.time() - t0
+            info_fed = db.db_info()
+            fin_fed = torch.zeros((n1, 5), dtype=torch.int16, device=dev)
+            db.query_device(rp, con, final_t=fin_fed, stream=st)
+            torch.cuda.synchronize()
+        same = {k_: info_file[k_] == info_fed[k_] for k_ in info_file}
+        assert torch.equal(fin_file, fin_fed), "file-loaded and chunk-fed tables classify differently"
+        assert all(same.values()), ("mc_db_info differs", {k_: (info_file[k_], info_fed[k_]) for k_, v in same.items() if not v})
+        out["load"]["equal_to_chunk_fed_build"] = True
+        out["load"]["chunk_fed_build_s"] = round(fed_s, 2)
+        print("file-loaded index == chunk-fed index (mc_db_info field by field, 1 M reads bit-identical); chunk-fed build %.1f s" % fed_s, flush=True)
+        torch.cuda.empty_cache()
+    del rp, con, fin_file
+
+    if a.load_times:
+        libs = [os.path.join(ROOT, "jn_cuclark_amd", "libmcclark.so")]
+        if os.path.exists(os.path.join(ROOT, "build", "libmcclark_r02.so")):
+            libs.append(os.path.join(ROOT, "build", "libmcclark_r02.so"))
+        lt = []
+        for members, mode in ((1, "auto"), (2, "shards"), (3, "shards")):
+            for lib in libs:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "load_time.py"), base, "--lib", lib,
+                                    "--members", str(members), "--mode", mode], capture_output=True, text=True)
+                line = (r.stdout.strip().split("\n") or [""])[-1] if r.returncode == 0 else "FAILED: " + (r.stdout + r.stderr)[-300:]
+                print(line, flush=True)
+                lt.append(line)
+        out["load_times"] = lt
+
+    # ---- 3. FASTQ -> CSV through the host driver -----------------------------------------------------------------
+    fq = os.path.join(work, "reads.fq")
+    t0 = time.time()
+    truth = synth_gpu.write_fastq(fq, genomes, a.reads, seed=91).numpy()
+    print("FASTQ: %d reads, %.2f GB, generated + written in %.1f s" % (a.reads, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
+    with open(os.path.join(work, "targets.txt"), "w") as f:
+        f.write("".join("%s/g%04d.fa\tT%04d\n" % (work, i, i) for i in range(T)))
+    for i in range(T):          # the driver checks that the target files exist (it builds from them when the database is missing)
+        with open("%s/g%04d.fa" % (work, i), "w") as f:
+            f.write(">g%04d\n" % i)
+    del genomes
+    torch.cuda.empty_cache()
+    exe = os.path.join(ROOT, "bin", "cuCLARK")
+    runs = []
+    for rep in range(2):
+        t0 = time.time()
+        r = subprocess.run([exe, "-k", str(K), "-T", os.path.join(work, "targets.txt"), "-D", work, "-O", fq, "-R", os.path.join(work, "res"),
+                            "-n", str(a.threads), "-b", str(a.batches), "--verbose"], capture_output=True, text=True)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            print(r.stderr[-3000:])
+            raise SystemExit("cuCLARK failed")
+        done = [l for l in r.stderr.split("\n") if "Done in" in l]
+        timing = [l for l in r.stderr.split("\n") if "timing" in l]
+        # "Done in 0.6s (3870967741 reads/min, 40000000 reads)": the seconds have one decimal, the rate is exact
+        rpm = float(done[0].split("(")[1].split(" reads/min")[0]) if done else float("nan")
+        secs = a.reads / (rpm / 60.0) if rpm == rpm and rpm > 0 else float("nan")
+        runs.append({"done_in_s": round(secs, 4), "Mreads_per_s": round(rpm / 60e6, 2), "wall_s": round(wall, 2),
+                     "line": done[0].strip() if done else "", "timing": timing})
+        print("run %d: wall %.1f s | %s | %s" % (rep, wall, done[0].strip() if done else "?", " | ".join(timing)), flush=True)
+    # the CSV: one line per read, planted reads assigned to their genome
+    csv = os.path.join(work, "res.csv")
+    n_lines = 0
+    good = bad = 0
+    with open(csv, "rb") as f:
+        f.readline()
+        for i, ln in enumerate(f):
+            n_lines += 1
+            if i < 200_000:
+                c = ln.split(b",")
+                assert c[0] == b"r%010d" % i, ln
+                good += c[-3] == b"T%04d" % truth[i]
+                bad += c[-3] != b"T%04d" % truth[i] and c[-3] != b"NA"
+    assert n_lines == a.reads and good > 199_000 and bad < 200, (n_lines, good, bad)
+    best = min(x["done_in_s"] for x in runs)
+    out["e2e_host"] = {"reads": a.reads, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "threads": a.threads, "batches": a.batches,
+                       "runs": runs, "Mreads_per_s": round(a.reads / best / 1e6, 2) if best == best and best > 0 else None,
+                       "csv_lines": n_lines, "first_200k_assigned_to_their_genome": good,
+                       "what": "bin/cuCLARK -k 31 -O reads.fq: FASTQ text -> index -> pack -> GPU -> CSV text, the program's own timer "
+                               "(the reference's, src/CuCLARK_hh.hh:552-563: the database load is outside it); wall_s = the whole process"}
+    print(json.dumps(out), flush=True)
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
