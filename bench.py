@@ -218,6 +218,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if rank == 0 and hasattr(db._lib, "mc_debug_stats"):
+        # a measurement build (tools/stats_build.sh, MC_LIB_PATH): where the lookups of one step end
+        import ctypes as C
+        arr = (C.c_ulonglong * 16)()
+        db._lib.mc_debug_stats(arr)
+        step()
+        torch.cuda.synchronize()
+        db._lib.mc_debug_stats(arr)
+        names = ["steps", "runs", "kmers_looked_up", "found_in_first_line", "missed_on_chained_line", "runs_on_overflowing_lines",
+                 "steps_with_such_a_miss", "steps_that_go_to_chains", "kmers_to_chains_after_bloom", "distinct_chain_lines_by_neighbours",
+                 "chain_fetch_rounds", "chain_lines_fetched", "found_in_chain"]
+        log("lookup stats per read: " + ", ".join("%s %.3f" % (nm, arr[i] / n_reads) for i, nm in enumerate(names)))
+
     total_reads = n_reads * args.steps * (1 if shard_mode else world)
     value = total_reads / elapsed / 1e6
 

@@ -292,7 +292,7 @@ int index_next_pass(mc_ctx *c)
     }
     HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
     HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_boff, c->d_mz_lines);
+    hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_boff, c->d_mz_lines, c->k);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->build.d_count, 0, (size_t)(n ? n : 1) * 4, st));      // the counters become the cursors
     HIPCHK(hipStreamSynchronize(st));
@@ -1223,6 +1223,18 @@ int mc_get_db_info(mc_ctx *c, mc_db_info *out)
     *out = c->info;
     return MC_OK;
 }
+
+#ifdef MC_MZ_STATS
+// measurement builds only: the counters of mc_minimizer.hpp (MZ_STAT), read and reset
+int mc_debug_stats(unsigned long long *out16)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(mc::mz::g_mz_stats), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mc::mz::g_mz_stats), z, sizeof z));
+    return MC_OK;
+}
+#endif
 
 int mc_get_stats(mc_ctx *c, mc_stats *out)
 {

@@ -38,11 +38,16 @@ namespace mz {
 static constexpr int MZ_LINE = 128;
 static constexpr int MZ_CAP = 12;
 static constexpr int MZ_EMAX = 3;                                        // extra lines chained to a primary line
-static constexpr uint32_t MZ_CHAIN_CAP = (uint32_t)MZ_CAP * (1 + MZ_EMAX);   // k-mers a line keeps (first + extra lines)
+// A line that overflows keeps MZ_CAP1 k-mers in its first line: slot 11 holds a 62-bit Bloom word over the k-mers that
+// live in its extra lines (round 2: 16 bits in the header -- with 5-8 k-mers behind a line a quarter of all misses
+// went on to the chain for nothing, and so did 6 reads in 10 that hit nothing at all, tools/stats_build.sh)
+static constexpr int MZ_CAP1 = MZ_CAP - 1;
+static constexpr uint32_t MZ_CHAIN_CAP = (uint32_t)MZ_CAP1 + (uint32_t)MZ_CAP * MZ_EMAX;   // k-mers a line keeps (first + extra lines)
 // dword 30 of a primary line: bits 0-1 = lines per chain (0..MZ_EMAX), bit 2 = a lookup also scans the chain behind
 // its own (some chain was full when the table was built), bits 3-7 = s: the line has 2^s chains and a k-mer's chain
-// is picked by a hash of the k-mer (0: one chain), bits 16-31 = Bloom word
+// is picked by a hash of the k-mer (0: one chain), bit 16 = the line has extra lines (the header of any other line is 0)
 static constexpr uint32_t MZ_HDR_LEN = 3u;
+static constexpr uint32_t MZ_HDR_CHAIN = 0x10000u;
 static constexpr uint32_t MZ_HDR_TWO = 4u;
 static constexpr uint32_t MZ_HDR_SEG_SHIFT = 3u, MZ_HDR_SEG_MASK = 31u;
 static constexpr uint32_t MZ_SEG_LOAD = 9u;          // k-mers aimed at per segment of MZ_EMAX * MZ_CAP = 36 slots (P(overflow) ~ 1e-12)
@@ -203,15 +208,24 @@ __device__ __forceinline__ uint32_t part_of(uint64_t K, uint32_t n_parts)
     return __umulhi(h, n_parts);
 }
 
-// A line's header (dword 30) = number of extra lines (bits 0-2) | spill flag (bit 3) | a 16-bit Bloom
-// word (high half) over the k-mers that live in those extra lines, two bits per k-mer (an overflowing line spills 1-3 k-mers as
-// a rule: 2-5 % false positives instead of 6-17 % with one bit).  A k-mer that is not in the first line
-// follows the chain only if both its bits are set, so nearly every miss ends at the first line.
-__device__ __forceinline__ uint32_t extra_mask(uint64_t c)
+// The Bloom word of an overflowing line (key slot 11 of its first line) over the k-mers that live in its extra lines:
+// three bits per k-mer out of 62 (an overflowing line spills 2-8 k-mers as a rule: 0.1-3 % false positives; the
+// 16-bit word in the header that round 2 had: 20-40 %).  A k-mer that is not in the first line follows the chain only if
+// all its bits are set, so nearly every miss ends at the first line.  The word must never equal a k-mer (the match
+// compares all 12 slots): its top two bits are ones -- above every canonical k-mer of k < 32 -- and for k = 32 its top
+// 32 bits are ones and only 32 bits carry the filter (a 32-mer that starts with sixteen A is canonical only if it ends
+// with sixteen T, i.e. only with all filter bits zero, and an overflowing line has some set).  Never all ones (= empty slot)
+// in the first case either: bit 61 stays clear.
+static constexpr uint64_t MZ_BLOOM_BASE = 0xC000000000000000ull, MZ_BLOOM_BASE32 = 0xFFFFFFFF00000000ull;
+__device__ __forceinline__ uint64_t bloom_bits(uint64_t c, bool k32)
 {
     const uint32_t h = ((uint32_t)c ^ (uint32_t)(c >> 32)) * 0x9E3779B1u;
-    return (0x10000u << (h >> 28)) | (0x10000u << ((h >> 24) & 15u));
+    const uint32_t lo = (1u << (h >> 27)) | (1u << ((h >> 17) & 31u));
+    if (k32) return (uint64_t)lo;
+    const uint32_t hi = 1u << ((((h >> 22) & 31u) * 29u) >> 5);          // bits 32 .. 60
+    return ((uint64_t)hi << 32) | lo;
 }
+__host__ __device__ __forceinline__ uint64_t bloom_base(uint32_t k) { return k >= 32u ? MZ_BLOOM_BASE32 : MZ_BLOOM_BASE; }
 
 // ---------------------------------------------------------------------------
 // index build from the raw bucket arrays (sizes u8, quotients, labels)
@@ -235,7 +249,7 @@ __device__ __forceinline__ uint32_t seg_of(uint64_t c, uint32_t seg_log)
 __host__ __device__ __forceinline__ uint32_t seg_log_of(uint32_t c)
 {
     if (c <= MZ_CHAIN_CAP) return 0u;
-    const uint32_t want = (c - (uint32_t)MZ_CAP + MZ_SEG_LOAD - 1u) / MZ_SEG_LOAD;      // segments at the aimed load
+    const uint32_t want = (c - (uint32_t)MZ_CAP1 + MZ_SEG_LOAD - 1u) / MZ_SEG_LOAD;      // segments at the aimed load
     uint32_t s = 1u;
     while ((1u << s) < want) s++;
     return s;
@@ -266,20 +280,22 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
             const uint32_t slot = atomicAdd(&count[l], 1u);       // PASS 1: the counters were reset; they end equal to PASS 0's
             if (PASS == 1) {
                 uint8_t *first = lines + (uint64_t)l * MZ_LINE;
-                if (slot < (uint32_t)MZ_CAP) {
+                uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
+                const uint32_t h0 = *reinterpret_cast<volatile uint32_t *>(hdr);       // low bits: written before this pass
+                const uint32_t cap1 = (h0 & MZ_HDR_CHAIN) ? (uint32_t)MZ_CAP1 : (uint32_t)MZ_CAP;   // an overflowing line: slot 11 is its Bloom word
+                if (slot < cap1) {
                     reinterpret_cast<uint64_t *>(first)[slot] = c;
                     reinterpret_cast<uint16_t *>(first + 8 * MZ_CAP)[slot] = labels[koff + j];
                 } else {
-                    uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
-                    atomicOr(hdr, extra_mask(c));
-                    const uint32_t h0 = *reinterpret_cast<volatile uint32_t *>(hdr);       // low bits: written before this pass
+                    if (!(h0 & MZ_HDR_CHAIN)) { atomicOr(failed, 2u); continue; }   // the first pass counted at most MZ_CAP k-mers here
+                    atomicOr(reinterpret_cast<unsigned long long *>(first) + MZ_CAP1, (unsigned long long)bloom_bits(c, k >= 32u));
                     const uint32_t seg_log = (h0 >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK;
                     uint8_t *chain0 = extra_lines + (uint64_t)hdr[1] * MZ_LINE;
                     if (seg_log == 0u) {                               // one chain, filled in arrival order
                         // The chain was sized from PASS 0's count of this line.  A second pass that is not the
                         // first one again (another table, a file that changed) must not write past it.
-                        if (slot >= (uint32_t)MZ_CAP * (1u + (h0 & MZ_HDR_LEN))) { atomicOr(failed, 2u); continue; }
-                        const uint32_t e = slot - MZ_CAP;
+                        if (slot >= (uint32_t)MZ_CAP1 + (uint32_t)MZ_CAP * (h0 & MZ_HDR_LEN)) { atomicOr(failed, 2u); continue; }
+                        const uint32_t e = slot - MZ_CAP1;
                         uint8_t *base = chain0 + (uint64_t)(e / MZ_CAP) * MZ_LINE;
                         reinterpret_cast<uint64_t *>(base)[e % MZ_CAP] = c;
                         reinterpret_cast<uint16_t *>(base + 8 * MZ_CAP)[e % MZ_CAP] = labels[koff + j];
@@ -330,14 +346,14 @@ void mz_scan_blocks_kernel(const uint32_t *blk, uint32_t n, uint64_t *off, uint6
 __host__ __device__ __forceinline__ uint32_t chain_len_of(uint32_t c)
 {
     if (c <= (uint32_t)MZ_CAP) return 0u;
-    const uint32_t ex = (c - 1u) / (uint32_t)MZ_CAP;          // ceil((c - CAP) / CAP)
+    const uint32_t ex = c / (uint32_t)MZ_CAP;                 // ceil((c - CAP1) / CAP): the first line keeps CAP1 = CAP - 1
     return ex > (uint32_t)MZ_EMAX ? (uint32_t)MZ_EMAX : ex;
 }
 // number of one-line chains (log2) of an overflowing, not crowded line: its k-mers beyond the first line go to the
 // chain their hash picks, so a lookup reads ONE extra line instead of walking up to three
 __host__ __device__ __forceinline__ uint32_t small_seg_log_of(uint32_t c)
 {
-    return c <= 2u * (uint32_t)MZ_CAP ? 0u : c <= 3u * (uint32_t)MZ_CAP ? 1u : 2u;
+    return c <= (uint32_t)MZ_CAP1 + (uint32_t)MZ_CAP ? 0u : c <= (uint32_t)MZ_CAP1 + 2u * (uint32_t)MZ_CAP ? 1u : 2u;
 }
 __host__ __device__ __forceinline__ uint32_t extras_of(uint32_t c)
 {
@@ -347,7 +363,7 @@ __host__ __device__ __forceinline__ uint32_t extras_of(uint32_t c)
     const uint32_t t = small_seg_log_of(c);
     return t ? (1u << t) + 1u : 1u;                                   // 2^t one-line chains + one spare line (>= chain_len_of(c))
 }
-__host__ __device__ __forceinline__ uint32_t spilled_of(uint32_t c) { return c > MZ_CHAIN_CAP ? c - (uint32_t)MZ_CAP : 0u; }
+__host__ __device__ __forceinline__ uint32_t spilled_of(uint32_t c) { return c > MZ_CHAIN_CAP ? c - (uint32_t)MZ_CAP1 : 0u; }
 
 // per workgroup of RL_BUCKETS lines: extra lines; overall: k-mers in segmented chains, overflowing lines, largest line, crowded lines
 static __global__ __launch_bounds__(RL_THREADS)
@@ -385,7 +401,7 @@ static __global__ void mz_sum_u32_kernel(const uint32_t *v, uint64_t n, unsigned
 
 // headers: dword 30 = extra lines | spill flag (the placing pass ORs the Bloom bits in), dword 31 = first extra line
 static __global__ __launch_bounds__(RL_THREADS)
-void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_extra_off, uint8_t *lines)
+void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_extra_off, uint8_t *lines, uint32_t k)
 {
     __shared__ uint32_t s_a[RL_THREADS / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * RL_BUCKETS + (uint64_t)threadIdx.x * RL_PER_THREAD;
@@ -396,8 +412,10 @@ void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_ext
     for (int i = 0; i < RL_PER_THREAD; i++) {
         if (b0 + i >= n) break;
         uint32_t *hdr = reinterpret_cast<uint32_t *>(lines + (b0 + i) * MZ_LINE) + 30;
-        hdr[0] = chain_len_of(c[i]) | (seg_log_of(c[i]) << MZ_HDR_SEG_SHIFT);
+        // (a line that does not overflow keeps header 0: "nothing behind this line" is one compare in the lookup)
+        hdr[0] = c[i] > (uint32_t)MZ_CAP ? (chain_len_of(c[i]) | (seg_log_of(c[i]) << MZ_HDR_SEG_SHIFT) | MZ_HDR_CHAIN) : 0u;
         hdr[1] = (uint32_t)o;
+        if (c[i] > (uint32_t)MZ_CAP) reinterpret_cast<uint64_t *>(lines + (b0 + i) * MZ_LINE)[MZ_CAP1] = bloom_base(k);
         o += extras_of(c[i]);
     }
 }
@@ -430,14 +448,15 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
             const uint32_t n = lane_bcast(n_mine, l);
             uint8_t *first = lines + i * MZ_LINE;
             uint8_t *more = extra_lines + (uint64_t)reinterpret_cast<const uint32_t *>(first)[31] * MZ_LINE;
-            auto slot_line = [&](uint32_t e) -> uint8_t * { return e < (uint32_t)MZ_CAP ? first : more + (uint64_t)(e / MZ_CAP - 1u) * MZ_LINE; };
+            // entry e as the placing pass left it: the first MZ_CAP1 in the first line, the rest in the chain, in order
             const bool have = lane < n;
             uint64_t key = ~0ull, mk = ~0ull;
             uint32_t lab = 0;
             if (have) {
-                const uint8_t *L = slot_line(lane);
-                key = reinterpret_cast<const uint64_t *>(L)[lane % MZ_CAP];
-                lab = reinterpret_cast<const uint16_t *>(L + 8 * MZ_CAP)[lane % MZ_CAP];
+                const uint32_t e = lane < (uint32_t)MZ_CAP1 ? lane : lane - (uint32_t)MZ_CAP1;
+                const uint8_t *L = lane < (uint32_t)MZ_CAP1 ? first : more + (uint64_t)(e / MZ_CAP) * MZ_LINE;
+                key = reinterpret_cast<const uint64_t *>(L)[e % MZ_CAP];
+                lab = reinterpret_cast<const uint16_t *>(L + 8 * MZ_CAP)[e % MZ_CAP];
                 mk = kmer_min_key(key, k, m);
             }
             // a group = the k-mers of ONE target that share the minimizer: what one read's run asks for (related
@@ -455,10 +474,10 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
             // chains, an entry in the chain its hash picks (seg_of) or -- that one is full -- in the line behind it,
             // so that a lookup reads one extra line, rarely two.  If some entry would land further away the line
             // falls back to one linear chain (read front to back, as all chains were before).
-            const bool over = have && rank >= (uint32_t)MZ_CAP;
-            const uint32_t n_over = n - (uint32_t)MZ_CAP;
+            const bool over = have && rank >= (uint32_t)MZ_CAP1;
+            const uint32_t n_over = n - (uint32_t)MZ_CAP1;
             uint32_t seg_log = small_seg_log_of(n);
-            uint32_t dst_line = over ? (rank - MZ_CAP) / MZ_CAP : 0u, dst_slot = over ? (rank - MZ_CAP) % MZ_CAP : 0u;   // linear
+            uint32_t dst_line = over ? (rank - MZ_CAP1) / MZ_CAP : 0u, dst_slot = over ? (rank - MZ_CAP1) % MZ_CAP : 0u;   // linear
             uint32_t len = (n_over + MZ_CAP - 1u) / MZ_CAP, two = 0u;
             uint32_t fill[6] = {0u, 0u, 0u, 0u, 0u, 0u};          // used slots of each extra line (wave-uniform)
             if (seg_log) {
@@ -492,13 +511,13 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // every entry is in registers before any is rewritten
             __builtin_amdgcn_wave_barrier();
-            uint32_t bloom = 0;
+            uint64_t bloom = 0;
             if (have) {
                 uint8_t *L = over ? more + (uint64_t)dst_line * MZ_LINE : first;
                 const uint32_t sl = over ? dst_slot : rank;
                 reinterpret_cast<uint64_t *>(L)[sl] = key;
                 reinterpret_cast<uint16_t *>(L + 8 * MZ_CAP)[sl] = (uint16_t)lab;
-                if (over) bloom = extra_mask(key);
+                if (over) bloom = bloom_bits(key, k >= 32u);
             }
             // slots of the extra lines that hold nothing (the placing pass wrote entries in arrival order there)
             const uint32_t n_alloc = extras_of(n);
@@ -507,10 +526,11 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
                 const uint32_t used = e == 0 ? fill[0] : e == 1 ? fill[1] : e == 2 ? fill[2] : e == 3 ? fill[3] : e == 4 ? fill[4] : fill[5];
                 if (sl >= used) reinterpret_cast<uint64_t *>(more + (uint64_t)e * MZ_LINE)[sl] = MZ_EMPTY;
             }
-            for (int o = 32; o > 0; o >>= 1) bloom |= (uint32_t)__shfl_xor((int)bloom, o, 64);
+            for (int o = 32; o > 0; o >>= 1) bloom |= __shfl_xor(bloom, o, 64);
             if (lane == 0) {
                 uint32_t *hdr = reinterpret_cast<uint32_t *>(first) + 30;
-                hdr[0] = len | two | (seg_log << MZ_HDR_SEG_SHIFT) | bloom;      // extra_mask() sits in the high half
+                hdr[0] = len | two | (seg_log << MZ_HDR_SEG_SHIFT) | MZ_HDR_CHAIN;
+                reinterpret_cast<uint64_t *>(first)[MZ_CAP1] = bloom_base(k) | bloom;        // key slot 11: the Bloom word
             }
         }
     }
@@ -568,6 +588,13 @@ void mz_sort_lines_kernel(uint8_t *lines, uint32_t n_lines)
 // ---------------------------------------------------------------------------
 // query
 // ---------------------------------------------------------------------------
+#ifdef MC_MZ_STATS      // measurement builds only (tools/stats_build.sh): where the lookups of a workload end
+__device__ unsigned long long g_mz_stats[16];
+#define MZ_STAT(i, v) do { if (__builtin_amdgcn_inverse_ballot_w64(1ull)) atomicAdd(&g_mz_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define MZ_STAT(i, v) do { } while (0)
+#endif
+
 struct MzArgs {
     QueryArgs q;               // reads, outputs, shard range, div, k, maxhits, flags (lines unused)
     const uint8_t *lines;      // the primary lines this context owns
@@ -1005,10 +1032,26 @@ void mz_query_kernel(const MzArgs A)
                             const uint64_t found = mask_ne(at, (uint32_t)MZ_CAP) & act;
                             if (__builtin_amdgcn_inverse_ballot_w64(found)) lab[s] = mz_line_label(Lm[s], at);
                             hitm[s] |= found;
-                            pend[s] = act & ~found & mask_gt_s(hd[s].hdr, 0xFFFFu);        // an empty Bloom word: no extra lines
+#ifdef MC_MZ_DEBUG_NOCHAIN      // measurement builds only (WRONG results): what the lookups behind the first line cost
+                            pend[s] = 0;
+#else
+                            pend[s] = act & ~found & mask_ne(hd[s].hdr, 0u);               // header 0: nothing behind this line
+#endif
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+#ifdef MC_MZ_STATS
+                        {
+                            MZ_STAT(0, 1);                                                        // batches (steps)
+                            MZ_STAT(1, nb);                                                       // runs
+                            MZ_STAT(2, __popcll(own[0]) + __popcll(own[1]));                      // k-mers looked up
+                            MZ_STAT(3, __popcll(hitm[0]) + __popcll(hitm[1]));                    // found in a first line
+                            MZ_STAT(4, __popcll(pend[0]) + __popcll(pend[1]));                    // missed on a line with a chain (before Bloom)
+                            const uint64_t ovl0 = __builtin_amdgcn_ballot_w64(leader[0] && (hd[0].hdr & MZ_HDR_LEN) != 0u);
+                            const uint64_t ovl1 = __builtin_amdgcn_ballot_w64(leader[1] && (hd[1].hdr & MZ_HDR_LEN) != 0u);
+                            MZ_STAT(5, __popcll(ovl0) + __popcll(ovl1));                          // runs on overflowing lines
+                        }
+#endif
                         if ((pend[0] | pend[1]) != 0) {
                             // Rare on a clean table: lines beyond the first.  A k-mer goes on only if both its Bloom
                             // bits are set; its chain is the one of the line's 2^s chains it hashes to (s = 0: the
@@ -1018,8 +1061,10 @@ void mz_query_kernel(const MzArgs A)
                             for (int s = 0; s < MZ_NS; s++) {
                                 xb[s] = 0; xn[s] = 0;
                                 if (__builtin_amdgcn_inverse_ballot_w64(pend[s])) {
-                                    const uint32_t hdr = hd[s].hdr, xm = extra_mask(c[s]);
-                                    if ((hdr & xm) == xm) {
+                                    const uint32_t hdr = hd[s].hdr;
+                                    const uint64_t xm = bloom_bits(c[s], k >= 32u);
+                                    const uint64_t bw = *reinterpret_cast<const uint64_t *>(Lm[s] + 8 * MZ_CAP1);      // the line's Bloom word
+                                    if ((bw & xm) == xm) {
                                         const uint32_t len = hdr & MZ_HDR_LEN;
                                         xn[s] = len << ((hdr >> 2) & 1u);
                                         xb[s] = hd[s].extra_base + seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * len;
@@ -1027,23 +1072,46 @@ void mz_query_kernel(const MzArgs A)
                                 }
                                 pend[s] = mask_ne(xn[s], 0u);
                             }
+#ifdef MC_MZ_STATS
+                            MZ_STAT(6, 1);                                                        // steps with a miss on a chained line
+                            if ((pend[0] | pend[1]) != 0) MZ_STAT(7, 1);                          // steps that go to the chains
+                            MZ_STAT(8, __popcll(pend[0]) + __popcll(pend[1]));                    // k-mers that go to the chains (after Bloom)
+                            {   // distinct chain lines among neighbours (what a per-line job numbering would fetch)
+                                const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)xb[1], 0x138, 0xf, 0xf, false);
+                                const uint64_t d0 = mask_ne(xb[0], pv) & pend[0], d1 = (mask_ne(xb[1], xb[0]) | ~pend[0]) & pend[1];
+                                MZ_STAT(9, __popcll(d0) + __popcll(d1));
+                            }
+#endif
                             // Round r looks at line r of each pending k-mer's chain, for both positions of every lane
                             // at once.  The lines are fetched exactly like first lines -- the pending lookups are
                             // numbered, publish their line, 8 lanes fetch one line, the lines are parked in LDS -- so a
                             // step pays ONE more memory round trip however many of its k-mers go on (six 16-byte loads
                             // per lane and position, one position after the other, before).
                             for (uint32_t r = 0; (pend[0] | pend[1]) != 0; r++) {
-                                const uint32_t n0 = (uint32_t)__popcll(pend[0]), n = n0 + (uint32_t)__popcll(pend[1]);
+                                // One job per chain LINE, not per k-mer: the pending k-mers of a run sit side by side and
+                                // mostly want the same line (round 2 fetched it once for each of them: 6.6 lines per read
+                                // on the genome-shaped table where 3.8 are distinct).  A pending position leads a job when
+                                // the position before it is not pending or wants another line -- as runs are numbered.
+                                const uint32_t pxb = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)xb[1], 0x138, 0xf, 0xf, false);
+                                const uint64_t d0 = pend[0] & (mask_ne(xb[0], pxb) | ~(pend[1] << 1));
+                                const uint64_t d1 = pend[1] & (mask_ne(xb[1], xb[0]) | ~pend[0]);
+                                const uint32_t n = (uint32_t)__popcll(d0) + (uint32_t)__popcll(d1);
                                 uint32_t job[MZ_NS];
-                                job[0] = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend[0] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend[0], 0u));
-                                job[1] = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(pend[1] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend[1], 0u));
+                                {
+                                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(d0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)d0, 0u))
+                                                         + __builtin_amdgcn_mbcnt_hi((uint32_t)(d1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)d1, 0u));
+                                    job[0] = below + (__builtin_amdgcn_inverse_ballot_w64(d0) ? 1u : 0u) - 1u;
+                                    job[1] = job[0] + (__builtin_amdgcn_inverse_ballot_w64(d1) ? 1u : 0u);
+                                }
                                 uint64_t found[MZ_NS] = {0ull, 0ull};
                                 for (uint32_t ch = 0; ch < n; ch += MZ_RUNS) {
+                                    MZ_STAT(10, 1);                                               // chain fetch rounds (of up to 32 lines)
+                                    MZ_STAT(11, n - ch < (uint32_t)MZ_RUNS ? n - ch : (uint32_t)MZ_RUNS);   // chain lines fetched
                                     uint64_t here[MZ_NS];
 #pragma unroll
                                     for (int s = 0; s < MZ_NS; s++) {
                                         here[s] = pend[s] & mask_lt_s(job[s] - ch, (uint32_t)MZ_RUNS);
-                                        if (__builtin_amdgcn_inverse_ballot_w64(here[s])) runline[job[s] - ch] = xb[s] + r;
+                                        if (__builtin_amdgcn_inverse_ballot_w64(here[s] & (s == 0 ? d0 : d1))) runline[job[s] - ch] = xb[s] + r;
                                     }
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
@@ -1065,6 +1133,8 @@ void mz_query_kernel(const MzArgs A)
                                     __builtin_amdgcn_wave_barrier();
                                 }
                                 // still pending: not found yet and another line in the chain
+#pragma unroll
+                                MZ_STAT(12, __popcll(found[0]) + __popcll(found[1]));            // found in a chain
 #pragma unroll
                                 for (int s = 0; s < MZ_NS; s++) {
                                     hitm[s] |= found[s];
