@@ -57,7 +57,8 @@ void free_db(mc_ctx *c)
     if (c->d_ovf_keys) (void)hipFree(c->d_ovf_keys);
     if (c->d_ovf_labels) (void)hipFree(c->d_ovf_labels);
     if (c->d_mz_lines) (void)hipFree(c->d_mz_lines);
-    if (c->d_mz_extra) (void)hipFree(c->d_mz_extra);
+    if (c->d_mz_extra && c->mz_extra_own_alloc) (void)hipFree(c->d_mz_extra);
+    c->mz_extra_own_alloc = false; c->mz_extra_reserved = 0;
     c->d_lines = nullptr; c->d_ovf_keys = nullptr; c->d_ovf_labels = nullptr;
     c->d_mz_lines = nullptr; c->d_mz_extra = nullptr;
     c->db_loaded = false;
@@ -135,7 +136,18 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     c->info = mc_db_info{};
     c->info.part = part; c->info.n_parts = n_parts;
     const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
-    if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess ||
+    // room for the extra lines behind the primary lines, in the same allocation (mc_internal.hpp): the share the
+    // loader's budget assumes for this fill (index_bytes), which a genome-shaped table stays below
+    uint64_t reserve = (uint64_t)((double)c->mz_n_local * mcint::extra_share(per_line)) + 64;
+    if (getenv("MC_MZ_NO_RESERVE")) reserve = 0;
+    if (hipMalloc(&c->d_mz_lines, lbytes + (size_t)reserve * mc::mz::MZ_LINE) != hipSuccess) {
+        (void)hipGetLastError();
+        reserve = 0;                                            // a tight card: the lines alone, the extra lines where they fit
+        c->d_mz_lines = nullptr;
+        if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess) { (void)hipGetLastError(); c->d_mz_lines = nullptr; }
+    }
+    c->mz_extra_reserved = reserve;
+    if (!c->d_mz_lines ||
         hipMalloc(&c->build.d_count, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess ||
         hipMalloc(&c->build.d_failed, 4) != hipSuccess) {
         (void)hipGetLastError();
@@ -285,7 +297,12 @@ int index_next_pass(mc_ctx *c)
     c->build.n_extra = acc; c->build.n_spilled = tot[0]; c->build.n_over = tot[1]; c->build.longest = (uint32_t)tot[2];
     c->build.n_crowded = tot[3];
     const size_t ebytes = (size_t)(acc ? acc : 1) * mc::mz::MZ_LINE;
-    if (hipMalloc(&c->d_mz_extra, ebytes) != hipSuccess) {
+    if (acc <= c->mz_extra_reserved && c->mz_extra_reserved) {
+        c->d_mz_extra = c->d_mz_lines + (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
+        c->mz_extra_own_alloc = false;
+    } else if (hipMalloc(&c->d_mz_extra, ebytes) == hipSuccess) {
+        c->mz_extra_own_alloc = true;
+    } else {
         (void)hipGetLastError();
         free_db(c); index_abort(c);
         return fail(MC_ENOMEM, "minimizer index: not enough HBM for the extra lines");
@@ -339,7 +356,7 @@ int index_end(mc_ctx *c)
     I.n_overflow_keys = c->build.n_spilled;
     I.line_bytes = mc::mz::MZ_LINE;
     I.line_capacity = mc::mz::MZ_CAP;
-    I.device_bytes = ((uint64_t)c->mz_n_local + c->build.n_extra) * mc::mz::MZ_LINE;
+    I.device_bytes = ((uint64_t)c->mz_n_local + c->mz_extra_reserved + (c->mz_extra_own_alloc ? c->build.n_extra : 0)) * mc::mz::MZ_LINE;
     I.index_kind = MC_INDEX_MINIMIZER;
     I.n_lines = (uint64_t)c->mz_n_local * c->mz_n_parts;                 // part p = lines [p * n, (p + 1) * n) of the table's
     I.line_begin = (uint64_t)c->mz_n_local * c->mz_part; I.line_end = I.line_begin + c->mz_n_local;
@@ -783,12 +800,18 @@ uint64_t lines_per_part(uint64_t n_keys_total, uint32_t n_parts, double fill)
     return per >= MZ_MAX_LINES ? 0 : per;
 }
 
+// extra lines per primary line the budget assumes at `fill` k-mers per line (measured on a genome-shaped table, which
+// overflows more than a random one)
+double extra_share(double fill)
+{
+    return fill <= 4.0 ? 0.12 : fill <= 5.0 ? 0.17 : fill <= 6.0 ? 0.22 : fill <= 7.0 ? 0.32 : fill <= 8.0 ? 0.45 : fill <= 10.0 ? 0.65 : 0.9;
+}
+
 // HBM one context needs for its share of a minimizer index at `fill` k-mers per line: lines, extra lines (the
 // share measured on a genome-shaped table, which overflows more than a random one), build counters
 uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill)
 {
-    const double extra = fill <= 4.0 ? 0.12 : fill <= 5.0 ? 0.17 : fill <= 6.0 ? 0.22 : fill <= 7.0 ? 0.32 : fill <= 8.0 ? 0.45
-                       : fill <= 10.0 ? 0.65 : 0.9;
+    const double extra = extra_share(fill);
     const double lines = ((double)n_keys_total / fill + 1024.0) / (double)n_parts;
     return (uint64_t)(lines * 128.0 * (1.0 + extra) + lines * 4.0) + (2ull << 30);
 }

@@ -105,6 +105,12 @@ struct mc_ctx {
     // lines do not fit in HBM)
     int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
     uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
+    // The extra lines live BEHIND the primary lines in the same allocation whenever the room reserved for them at
+    // mc_index_begin (the loader's estimate of their share) suffices: an allocation of its own, made after the first
+    // build pass from a heap that the build's temporaries have cut up, ends up on small pages, and a fetch from it costs
+    // several times a fetch from the primary lines (62-200 ns against 24 ns per line)
+    uint64_t mz_extra_reserved = 0;    // extra lines reserved behind the primary lines
+    bool mz_extra_own_alloc = false;   // d_mz_extra is an allocation of its own (the reserve did not suffice)
     uint32_t mz_n_local = 0;           // primary lines held here (every part of a table has the same number)
     uint32_t mz_part = 0, mz_n_parts = 1, mz_m = 0;
     double fill_hint = 0.0;            // k-mers per line chosen by a group loader for all its members (0 = choose here)
@@ -177,6 +183,7 @@ bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total);
 // lines_per_part: primary lines of ONE part at `fill` k-mers per line; 0 when that exceeds the 32-bit line index.
 uint64_t lines_per_part(uint64_t n_keys_total, uint32_t n_parts, double fill);
 uint64_t index_bytes(uint64_t n_keys_total, uint32_t n_parts, double fill);
+double extra_share(double fill);
 // the sparsest fill in [4, 12] whose share fits `free_bytes` (16 GB kept in reserve) AND the line index
 double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes);
 // smallest part count in [1, max_parts] whose share fits at a fill of at most `max_fill`; 0 = none does

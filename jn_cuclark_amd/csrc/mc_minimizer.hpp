@@ -209,21 +209,27 @@ __device__ __forceinline__ uint32_t part_of(uint64_t K, uint32_t n_parts)
 }
 
 // The Bloom word of an overflowing line (key slot 11 of its first line) over the k-mers that live in its extra lines:
-// three bits per k-mer out of 62 (an overflowing line spills 2-8 k-mers as a rule: 0.1-3 % false positives; the
-// 16-bit word in the header that round 2 had: 20-40 %).  A k-mer that is not in the first line follows the chain only if
-// all its bits are set, so nearly every miss ends at the first line.  The word must never equal a k-mer (the match
-// compares all 12 slots): its top two bits are ones -- above every canonical k-mer of k < 32 -- and for k = 32 its top
-// 32 bits are ones and only 32 bits carry the filter (a 32-mer that starts with sixteen A is canonical only if it ends
-// with sixteen T, i.e. only with all filter bits zero, and an overflowing line has some set).  Never all ones (= empty slot)
+// two bits per k-mer, one in each half of the word (31 + 29 usable bits; an overflowing line spills 2-8 k-mers as a
+// rule: 0.4-5 % false positives; the 16-bit word in the header that round 2 had: 20-40 %).  A k-mer that is not in the
+// first line follows the chain only if both its bits are set, so nearly every miss ends at the first line.  The word
+// must never equal a k-mer (the match compares all 12 slots): its top two bits are ones -- above every canonical k-mer
+// of k < 32 -- and for k = 32 its top 32 bits are ones and only the low half carries the filter (a 32-mer that starts
+// with sixteen A is canonical only if it ends with sixteen T, i.e. only with all filter bits zero, and an overflowing
+// line has some set; the test below needs no switch: the upper half always passes).  Never all ones (= empty slot)
 // in the first case either: bit 61 stays clear.
 static constexpr uint64_t MZ_BLOOM_BASE = 0xC000000000000000ull, MZ_BLOOM_BASE32 = 0xFFFFFFFF00000000ull;
-__device__ __forceinline__ uint64_t bloom_bits(uint64_t c, bool k32)
+__device__ __forceinline__ uint32_t bloom_hash(uint64_t c) { return ((uint32_t)c ^ (uint32_t)(c >> 32)) * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t bloom_hi_bit(uint32_t h) { const uint32_t b = (h >> 22) & 31u; return b < 28u ? b : 28u; }
+__device__ __forceinline__ uint64_t bloom_bits(uint64_t c, bool k32)       // build side
 {
-    const uint32_t h = ((uint32_t)c ^ (uint32_t)(c >> 32)) * 0x9E3779B1u;
-    const uint32_t lo = (1u << (h >> 27)) | (1u << ((h >> 17) & 31u));
-    if (k32) return (uint64_t)lo;
-    const uint32_t hi = 1u << ((((h >> 22) & 31u) * 29u) >> 5);          // bits 32 .. 60
-    return ((uint64_t)hi << 32) | lo;
+    const uint32_t h = bloom_hash(c);
+    const uint64_t lo = 1u << (h >> 27);
+    return k32 ? lo : (lo | ((uint64_t)(1u << bloom_hi_bit(h)) << 32));
+}
+__device__ __forceinline__ bool bloom_pass(uint64_t word, uint64_t c)       // lookup side: 9 VALU operations
+{
+    const uint32_t h = bloom_hash(c);
+    return (((uint32_t)word >> (h >> 27)) & ((uint32_t)(word >> 32) >> bloom_hi_bit(h)) & 1u) != 0u;
 }
 __host__ __device__ __forceinline__ uint64_t bloom_base(uint32_t k) { return k >= 32u ? MZ_BLOOM_BASE32 : MZ_BLOOM_BASE; }
 
@@ -1056,21 +1062,33 @@ void mz_query_kernel(const MzArgs A)
                             // Rare on a clean table: lines beyond the first.  A k-mer goes on only if both its Bloom
                             // bits are set; its chain is the one of the line's 2^s chains it hashes to (s = 0: the
                             // only one), plus the one behind it when header bit 2 says that some chain was full.
-                            uint32_t xb[MZ_NS], xn[MZ_NS];          // first line of the k-mer's chain, lines to look at
+                            // first the filter alone -- most steps with a miss on such a line end here (9 reads in 10 of
+                            // a genome-shaped table get this far, 6 in 10 further) --, then, for what passed, the chain
 #pragma unroll
                             for (int s = 0; s < MZ_NS; s++) {
-                                xb[s] = 0; xn[s] = 0;
-                                if (__builtin_amdgcn_inverse_ballot_w64(pend[s])) {
-                                    const uint32_t hdr = hd[s].hdr;
-                                    const uint64_t xm = bloom_bits(c[s], k >= 32u);
-                                    const uint64_t bw = *reinterpret_cast<const uint64_t *>(Lm[s] + 8 * MZ_CAP1);      // the line's Bloom word
-                                    if ((bw & xm) == xm) {
-                                        const uint32_t len = hdr & MZ_HDR_LEN;
+                                bool go = false;
+                                if (__builtin_amdgcn_inverse_ballot_w64(pend[s]))
+                                    go = bloom_pass(*reinterpret_cast<const uint64_t *>(Lm[s] + 8 * MZ_CAP1), c[s]);      // the line's Bloom word
+                                pend[s] = __builtin_amdgcn_ballot_w64(go);
+                            }
+                            uint32_t xb[MZ_NS] = {0u, 0u}, xn[MZ_NS] = {0u, 0u};          // first line of the k-mer's chain, lines to look at
+                            if ((pend[0] | pend[1]) != 0) {
+                                bool seg_any = false;
+#pragma unroll
+                                for (int s = 0; s < MZ_NS; s++) {
+                                    if (__builtin_amdgcn_inverse_ballot_w64(pend[s])) {
+                                        const uint32_t hdr = hd[s].hdr, len = hdr & MZ_HDR_LEN;
                                         xn[s] = len << ((hdr >> 2) & 1u);
-                                        xb[s] = hd[s].extra_base + seg_of(c[s], (hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * len;
+                                        xb[s] = hd[s].extra_base;
+                                        seg_any = seg_any || (hdr & (MZ_HDR_SEG_MASK << MZ_HDR_SEG_SHIFT)) != 0u;
                                     }
                                 }
-                                pend[s] = mask_ne(xn[s], 0u);
+                                if (__builtin_amdgcn_ballot_w64(seg_any) != 0) {          // hashed chains: rare
+#pragma unroll
+                                    for (int s = 0; s < MZ_NS; s++)
+                                        if (__builtin_amdgcn_inverse_ballot_w64(pend[s]))
+                                            xb[s] += seg_of(c[s], (hd[s].hdr >> MZ_HDR_SEG_SHIFT) & MZ_HDR_SEG_MASK) * (hd[s].hdr & MZ_HDR_LEN);
+                                }
                             }
 #ifdef MC_MZ_STATS
                             MZ_STAT(6, 1);                                                        // steps with a miss on a chained line
