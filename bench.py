@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica",
                     help="N>1: replica = DB on every GPU, reads split; shard = DB split by bucket "
                          "range, every GPU sees every read, sparse rows exchanged over RCCL")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="--mode shard: parts the table is cut into (0 = one group of all ranks); the ranks form "
+                         "world // shards groups that each hold the whole table and classify their own batches "
+                         "(jn_cuclark_amd.dist.shard_groups), rows are exchanged inside a group")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3],
                     help="BASELINE.json configs[]: 3 = full table, k=31, 10M reads (default, the metric's "
                          "configuration); 2 = cuCLARK-l light table (~4 GB on disk), k=27, 1M reads")
@@ -68,6 +72,11 @@ def main():
                     help="N>1 replica runs also exercise the sharded RCCL path once, untimed; skip that")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
     ap.add_argument("--verify", type=int, default=20000, help="reads checked against the oracle (0 = none)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1 runs of the headline workload also report, as extra keys of the JSON line (never the value): "
+                         "`genomes` -- the same kernel on the genome-shaped table of --db genomes -- and `e2e_host` -- the "
+                         "table written as .sz/.ky/.lb files, loaded by bin/cuCLARK, a FASTQ file classified to CSV; skip them")
+    ap.add_argument("--e2e-reads", type=int, default=40_000_000, help="reads in the FASTQ file of `e2e_host`")
     args = ap.parse_args()
     if args.config == 2:
         args.htsize, args.k, args.lam, args.targets, args.genome_len = 57777779, 27, 10.4, 2048, 14000
@@ -79,6 +88,9 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    if os.environ.get("BENCH_TRACE_AFTER"):          # where does a run sit after N seconds (a rehearsal that seems to hang)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_TRACE_AFTER"]), exit=False)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +115,13 @@ def main():
 
     k, ht = args.k, args.htsize
     shard_mode = world > 1 and args.mode == "shard"
+    # sharded: S parts x G groups; rank r holds part r % S for group r // S (ranks past S * G idle)
+    S, G, group, gi, part = 1, world, None, rank, 0
+    if shard_mode:
+        from jn_cuclark_amd.dist import shard_groups
+        S = args.shards if 0 < args.shards <= world else world
+        group, gi, part, G = shard_groups(S)
+    active = (not shard_mode) or group is not None
 
     # ---- database in HBM ---------------------------------------------------------
     t0 = time.time()
@@ -126,7 +145,7 @@ def main():
         if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.verify == 0):
             raw_host = tuple(np.concatenate([c[i] for c in host]) for i in range(3))
         # line-range parts when sharded: every rank streams the whole table and keeps its lines
-        db.read_chunks(lambda: host, n_keys, part=rank if shard_mode else 0, n_parts=world if shard_mode else 1, device=False)
+        db.read_chunks(lambda: host, n_keys, part=part if shard_mode else 0, n_parts=S if shard_mode else 1, device=False)
         del host
         genomes = genomes_h.to(dev)
         del genomes_h
@@ -156,7 +175,7 @@ def main():
                 host_parts.append((d_sz.cpu().numpy(), d_keys.cpu().numpy(), d_labels.cpu().numpy()))
         nonempty = nonzero / ht
         torch.cuda.empty_cache()
-        db.read_chunks(synth_chunks, n_keys, part=rank if shard_mode else 0, n_parts=world if shard_mode else 1, device=True)
+        db.read_chunks(synth_chunks, n_keys, part=part if shard_mode else 0, n_parts=S if shard_mode else 1, device=True)
         if want_host:
             raw_host = tuple(np.concatenate([p_[i] for p_ in host_parts]) for i in range(3))
         del host_parts
@@ -173,18 +192,20 @@ def main():
 
     # ---- reads in HBM ------------------------------------------------------------
     n_reads = args.reads
-    read_seed = 32 if shard_mode else 32 + rank      # shards see the SAME batch
+    read_seed = 32 + max(gi, 0) if shard_mode else 32 + rank      # the shards of a group see the SAME batch
     rp_t, con_t = synth_gpu.make_reads(genomes, n_reads, args.read_len, seed=read_seed)
     fin_t = torch.zeros((n_reads, 5), dtype=torch.int16, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     sharded = None
     if shard_mode:
         from jn_cuclark_amd.dist import ShardedClassifier, HipBackend
-        sharded = ShardedClassifier(HipBackend(db, dev))
+        sharded = ShardedClassifier(HipBackend(db, dev), group=group) if active else None
 
     def step():
         if not shard_mode:
             db.query_device(rp_t, con_t, final_t=fin_t, stream=stream)
+            return
+        if not active:
             return
         # every GPU: partial sparse rows of ALL reads for its line range of the index, chunk by chunk; per chunk
         # a reduce-scatter by read range over xGMI (all_to_all) + k-way merge + top-2 on the owner, on a
@@ -231,7 +252,7 @@ def main():
                  "chain_fetch_rounds", "chain_lines_fetched", "found_in_chain"]
         log("lookup stats per read: " + ", ".join("%s %.3f" % (nm, arr[i] / n_reads) for i, nm in enumerate(names)))
 
-    total_reads = n_reads * args.steps * (1 if shard_mode else world)
+    total_reads = n_reads * args.steps * (G if shard_mode else world)
     value = total_reads / elapsed / 1e6
 
     out = None
@@ -266,7 +287,7 @@ def main():
             "metric": "Mreads/s classified, %dbp k=%d %s" % (args.read_len, k, "RefSeq-bacteria-scale DB" if ht == HTSIZE else "DB"),
             "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if shard_mode else "weak",
+            "higher_is_better": True, "scaling": "strong" if (shard_mode and G == 1) else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {
                 "workload": "cuCLARK full table HTSIZE=%d k=%d, %.2fe9 k-mers of %d targets in HBM (%s; "
@@ -281,9 +302,9 @@ def main():
                           "lines_overflowing_frac": round(info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]), 5),
                           "lines_crowded": info["n_lines_crowded"], "kmers_in_hashed_chains": info["n_spilled_keys"],
                           "largest_line_kmers": info["largest_line"], "hbm_bytes": info["device_bytes"]},
-                "reads_per_step": n_reads * (1 if shard_mode else world), "k": k, "htsize": ht,
+                "reads_per_step": n_reads * (G if shard_mode else world), "k": k, "htsize": ht,
                 "n_kmers_db": n_keys, "targets": args.targets, "maxhits": MAXHITS,
-                "parallelism": ("line-shard%d+all_to_all" % world) if shard_mode else ("replica%d" % world),
+                "parallelism": ("%d parts x %d groups, all_to_all inside a group" % (S, G)) if shard_mode else ("replica%d" % world),
                 "kmer_hit_rate": None if hit_rate != hit_rate else round(hit_rate, 4),
                 "reads_assigned": round(assigned, 4), "reads_over_maxhits": st["reads_over_maxhits"],
             },
@@ -359,6 +380,20 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
 
+    # ---- secondary measurements in the same line (N = 1, headline workload; never the value) ------------------
+    if rank == 0 and world == 1 and not args.no_extras and args.db == "synthetic" and args.config == 3 and args.read_len == READ_LEN:
+        db.close()
+        del rp_t, con_t, fin_t
+        torch.cuda.empty_cache()
+        for name, fn in (("genomes", extra_genomes), ("e2e_host", extra_e2e_host)):
+            t1 = time.time()
+            try:
+                out[name] = fn(args, torch, np, dev, dev_index, genomes)
+            except Exception as e:          # the headline measurement must survive a failure here
+                out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            log("%s: %.1f s" % (name, time.time() - t1))
+            torch.cuda.empty_cache()
+
     # the ONE JSON line goes out before anything that is not part of the measurement can stall
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -406,6 +441,115 @@ def source_sha():
             h.update(open(f, "rb").read())
         _SHA = h.hexdigest()[:16]
     return _SHA
+
+
+def extra_genomes(args, torch, np, dev, dev_index, _genomes):
+    """The query kernel on the genome-shaped table (`--db genomes`: every stored k-mer from structured genomes -- genera with
+    shared sequence, a conserved block, tandem repeats, poly-A), 10 M reads per launch as the headline, checked against
+    the oracle.  What a real RefSeq table looks like to the index; the headline table is kinder to it."""
+    from jn_cuclark_amd import CuClarkDB, synth_gpu
+    k, ht, T = args.k, args.htsize, args.targets
+    genomes = synth_gpu.make_structured_genomes(T, 1_500_000, seed=31, device=dev)
+    chunks, n_keys = synth_gpu.build_genome_db(genomes, k, ht)
+    host = [(c[0].cpu().numpy(), c[1].cpu().numpy(), c[2].cpu().numpy(), c[3], c[4]) for c in chunks]
+    del chunks
+    genomes_h = genomes.cpu()
+    del genomes
+    torch.cuda.empty_cache()
+    db = CuClarkDB(k=k, numBatches=1, numTargets=T, device=dev_index, htsize=ht, maxhits=MAXHITS)
+    try:
+        db.read_chunks(lambda: host, n_keys, device=False)
+        info = db.db_info()
+        genomes = genomes_h.to(dev)
+        n_reads = args.reads
+        rp_t, con_t = synth_gpu.make_reads(genomes, n_reads, READ_LEN, seed=32)
+        fin_t = torch.zeros((n_reads, 5), dtype=torch.int16, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            db.query_device(rp_t, con_t, final_t=fin_t, stream=stream)
+        torch.cuda.synchronize()
+        steps = 5
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record()
+            db.query_device(rp_t, con_t, final_t=fin_t, stream=stream)
+            ev[i][1].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kern = sum(a.elapsed_time(b) for a, b in ev) / steps
+        res = {"value": round(n_reads * steps / dt / 1e6, 2), "unit": "Mreads/s", "kernel_ms": round(kern, 4), "steps": steps,
+               "reads_per_step": n_reads, "n_kmers_db": n_keys,
+               "index": {"lines": info["line_end"] - info["line_begin"], "extra_lines": info["n_extra_lines"],
+                         "kmers_per_line": round(n_keys / max(1, info["n_lines"]), 2),
+                         "lines_overflowing_frac": round(info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]), 5),
+                         "lines_crowded": info["n_lines_crowded"], "largest_line_kmers": info["largest_line"], "hbm_bytes": info["device_bytes"]},
+               "what": "the same kernel, 10 M x 150 bp per launch, on a table whose EVERY k-mer comes from structured genomes "
+                       "(4096 x 1.5 Mb: genera of 4 with shared sequence, a conserved block, tandem repeats, poly-A)"}
+        if args.verify:
+            from oracle import pyoracle
+            fin = fin_t.cpu().numpy().view(np.uint16)
+            raw = tuple(np.concatenate([c[i] for c in host]) for i in range(3))
+            odb = pyoracle.OracleDB.from_arrays(ht, raw[0], raw[1].view(np.uint32), raw[2].view(np.uint16))
+            del raw
+            rp_h = rp_t.cpu().numpy().view(np.uint32)
+            con_h = con_t.cpu().numpy().view(np.uint16)
+            per_read = con_h.size // n_reads
+            for idx0 in (0, n_reads - args.verify):
+                p = (np.arange(args.verify + 1, dtype=np.uint64) * np.uint64(per_read)).astype(np.uint32)
+                want, _ = odb.classify(k, p, con_h[idx0 * per_read:(idx0 + args.verify) * per_read], MAXHITS)
+                if not np.array_equal(want, fin[idx0:idx0 + args.verify]):
+                    raise SystemExit("bench: HIP results on the genome-shaped table differ from the oracle")
+            odb.close()
+            res["verified_reads_vs_oracle"] = 2 * args.verify
+        return res
+    finally:
+        db.close()
+
+
+def extra_e2e_host(args, torch, np, dev, dev_index, genomes):
+    """File to CSV through the host driver at the metric's size: the headline table written in the reference's on-disk
+    format (.sz/.ky/.lb, 41 GB), a FASTQ file of --e2e-reads reads, `bin/cuCLARK -k 31 -O reads.fq -R res`: the
+    program's own timer (the reference's, src/CuCLARK_hh.hh:552-563: FASTQ text -> index -> pack -> GPU -> CSV text, the
+    database load outside it), the load it did before (wall clock of the whole process minus that), the CSV checked
+    against the ground truth.  Skipped, with the reason, when no directory has room for the files."""
+    import shutil
+    from jn_cuclark_amd import synth_gpu
+    k, ht, T = args.k, args.htsize, args.targets
+    need = int(6.5e9 * 6.3) + ht + args.e2e_reads * (synth_gpu.FASTQ_RECORD + 40)
+    d = synth_gpu.pick_dir(need)
+    if d is None:
+        return {"skipped": "no directory with %.0f GB free for the database files and the FASTQ file" % (need / 1e9)}
+    work = os.path.join(d, "mc_bench_e2e_%d" % os.getpid())
+    os.makedirs(work, exist_ok=True)
+    try:
+        base = os.path.join(work, "db_central_k%d_t%d_s%d_m0.tsk" % (k, T, ht))
+        ranges = [(ht * j // 16, ht * (j + 1) // 16) for j in range(16)]
+
+        def chunks():
+            for b0, b1 in ranges:
+                d_sz, d_keys, d_labels = synth_gpu.build_db(dev, 31, k, ht, T, args.lam, genomes=genomes, shard=(b0, b1))
+                yield d_sz, d_keys, d_labels, b0, b1
+
+        t0 = time.time()
+        n_keys, nbytes = synth_gpu.write_db_files(base, chunks())
+        t_db = time.time() - t0
+        fq = os.path.join(work, "reads.fq")
+        truth = synth_gpu.write_fastq(fq, genomes, args.e2e_reads, seed=91).numpy()
+        torch.cuda.empty_cache()
+        r = synth_gpu.host_driver_run(os.path.join(ROOT, "bin", "cuCLARK"), work, k, T, fq, args.e2e_reads, threads=16, batches=32, truth=truth)
+        ok = r["csv_lines"] == args.e2e_reads and r["assigned_to_their_genome"] > 0.995 * r["checked"] and r["assigned_elsewhere"] < 200
+        if not ok:
+            raise SystemExit("bench: the host driver's CSV fails the ground-truth check: %r" % (r,))
+        return {"value": r["Mreads_per_s"], "unit": "Mreads/s", "reads": args.e2e_reads, "seconds": r["seconds"],
+                "process_wall_s": r["wall_s"], "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "db_files_GB": round(nbytes / 1e9, 1),
+                "db_files_in": d, "db_files_written_s": round(t_db, 1), "threads": 16, "batches": 32, "line": r["line"],
+                "csv_lines": r["csv_lines"], "first_reads_checked": r["checked"], "assigned_to_their_genome": r["assigned_to_their_genome"],
+                "what": "bin/cuCLARK -k 31 on a FASTQ file against the headline table loaded from its .sz/.ky/.lb files: the program's own "
+                        "timer (FASTQ text -> CSV text; the reference's, src/CuCLARK_hh.hh:552-563), process_wall_s = with process start and "
+                        "the database load (mc_group_load_db of 41 GB of files)"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def pipelined_rate(db, torch, np, rp_t, con_t, n_reads, fin_expected, nb=4, rounds=5):
@@ -465,8 +609,12 @@ def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend
     import time as _t
     try:
         from jn_cuclark_amd import CuClarkDB, synth_gpu
-        from jn_cuclark_amd.dist import ShardedClassifier, HipBackend
+        from jn_cuclark_amd.dist import ShardedClassifier, HipBackend, shard_groups
         k, ht, T, lam, n = 29, 200000033, 512, 3.75, 2_000_000
+        # 4 ranks and more: 2 parts x world/2 groups (every group holds the whole table, rows are exchanged inside it);
+        # fewer: one group of `world` parts
+        S = 2 if world >= 4 and world % 2 == 0 else world
+        group, gi, part, G = shard_groups(S)
         genomes = synth_gpu.make_genomes(T, 50_000, seed=41, device=dev)
         rp, con = synth_gpu.make_reads(genomes, n, READ_LEN, seed=42)
         full = synth_gpu.build_db(dev, 41, k, ht, T, lam, genomes=genomes)
@@ -476,9 +624,9 @@ def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend
             dbf.query_device(rp, con, final_t=want, stream=torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
         with CuClarkDB(k=k, numBatches=1, numTargets=T, device=dev_index, htsize=ht, maxhits=15) as dbs:
-            dbs.read_chunks(lambda: [(full[0], full[1], full[2], 0, ht)], int(full[1].numel()), part=rank, n_parts=world, device=True)
+            dbs.read_chunks(lambda: [(full[0], full[1], full[2], 0, ht)], int(full[1].numel()), part=part, n_parts=S, device=True)
             del full
-            sc = ShardedClassifier(HipBackend(dbs, dev))
+            sc = ShardedClassifier(HipBackend(dbs, dev), group=group)
             fin, ranges = sc.classify(rp, con, n)
             torch.cuda.synchronize()
             ok = bool(torch.equal(fin, torch.cat([want[lo:hi] for lo, hi in ranges])))
@@ -492,8 +640,9 @@ def shard_path_check(args, dist, torch, np, dev, dev_index, rank, world, backend
             dt = _t.perf_counter() - t0
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return {"verified_equal_to_unsharded": bool(flag.item()), "Mreads_per_s": round(n * steps / dt / 1e6, 2),
-                "table": "HTSIZE=%d k=%d, %d line-range parts, %d reads/step in 4 chunks, all_to_all of %d-byte rows" % (ht, k, world, n, 2 * dbs.row_len)}
+        return {"verified_equal_to_unsharded": bool(flag.item()), "Mreads_per_s": round(n * steps * G / dt / 1e6, 2),
+                "table": "HTSIZE=%d k=%d, %d parts x %d groups, %d reads/step and group in 4 chunks, all_to_all of %d-byte rows inside a group"
+                         % (ht, k, S, G, n, 2 * dbs.row_len)}
     except Exception as e:      # the headline measurement must survive a failure here
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 

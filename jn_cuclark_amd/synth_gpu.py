@@ -348,3 +348,61 @@ def write_fastq(path, genomes, n_reads, seed, planted_frac=0.5, sub_rate=0.01, s
             rec.cpu().numpy().tofile(f)
             del rec, codes
     return torch.cat(truth) if truth else torch.zeros(0, dtype=torch.int64)
+
+
+def pick_dir(need_bytes, want=None):
+    """a directory with `need_bytes` (+ 8 GB) free: `want`, /dev/shm, $TMPDIR, /tmp; None when there is none"""
+    import shutil
+    for d in ([want] if want else []) + ["/dev/shm", os.environ.get("TMPDIR") or "/tmp", "/tmp"]:
+        try:
+            if d and os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes + (8 << 30):
+                return d
+        except OSError:
+            pass
+    return None
+
+
+def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches=32, truth=None, check=200_000):
+    """`exe -k K -T targets -D work -O fastq -R work/res` (the database files must be in `work` under the reference's
+    name, src/CuCLARK_hh.hh:586-590): returns the program's own rate ("Done in Xs (N reads/min, M reads)", the
+    reference's timer, src/CuCLARK_hh.hh:552-563, :1931-1939: file -> CSV, the database load is outside it), the wall
+    clock of the whole process and -- with `truth` (source genome of the leading reads) -- how many of the first `check`
+    CSV lines name their genome."""
+    import subprocess
+    import time as _t
+    with open(os.path.join(work, "targets.txt"), "w") as f:
+        f.write("".join("%s/g%04d.fa\tT%04d\n" % (work, i, i) for i in range(n_targets)))
+    for i in range(n_targets):          # the driver checks that the target files exist (it builds from them when the database is missing)
+        p = "%s/g%04d.fa" % (work, i)
+        if not os.path.exists(p):
+            with open(p, "w") as f:
+                f.write(">g%04d\n" % i)
+    t0 = _t.time()
+    r = subprocess.run([exe, "-k", str(k), "-T", os.path.join(work, "targets.txt"), "-D", work, "-O", fastq, "-R", os.path.join(work, "res"),
+                        "-n", str(threads), "-b", str(batches), "--verbose"], capture_output=True, text=True)
+    wall = _t.time() - t0
+    if r.returncode != 0:
+        raise RuntimeError("host driver failed: " + r.stderr[-500:])
+    done = [ln for ln in r.stderr.split("\n") if "Done in" in ln]
+    timing = [ln.strip() for ln in r.stderr.split("\n") if "timing" in ln]
+    # "Done in 0.6s (3870967741 reads/min, 40000000 reads)": the seconds have one decimal, the rate is exact
+    rpm = float(done[0].split("(")[1].split(" reads/min")[0]) if done else float("nan")
+    out = {"reads": n_reads, "Mreads_per_s": round(rpm / 60e6, 2), "seconds": round(n_reads / (rpm / 60.0), 4) if rpm == rpm and rpm > 0 else None,
+           "wall_s": round(wall, 2), "line": done[0].strip() if done else "", "timing": timing, "threads": threads, "batches": batches}
+    n_lines = good = bad = 0
+    with open(os.path.join(work, "res.csv"), "rb") as f:
+        f.readline()
+        for i, ln in enumerate(f):
+            n_lines += 1
+            if truth is not None and i < min(check, len(truth)):
+                c = ln.split(b",")
+                if c[0] != b"r%010d" % i:
+                    raise RuntimeError("CSV line %d names %r" % (i, c[0]))
+                good += c[-3] == b"T%04d" % truth[i]
+                bad += c[-3] != b"T%04d" % truth[i] and c[-3] != b"NA"
+    out["csv_lines"] = n_lines
+    if truth is not None:
+        out["checked"] = min(check, len(truth))
+        out["assigned_to_their_genome"] = int(good)
+        out["assigned_elsewhere"] = int(bad)
+    return out

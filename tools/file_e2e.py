@@ -29,16 +29,6 @@ from jn_cuclark_amd import CuClarkDB, synth_gpu
 K, HT, T, LAM, GLEN, MAXHITS = 31, 1610612741, 4096, 3.75, 100_000, 15
 
 
-def pick_dir(need_bytes, want=None):
-    for d in ([want] if want else []) + ["/dev/shm", os.environ.get("TMPDIR") or "/tmp", "/tmp", ROOT]:
-        try:
-            if d and os.path.isdir(d) and shutil.disk_usage(d).free > need_bytes + (8 << 30):
-                return d
-        except OSError:
-            pass
-    return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=40_000_000)
@@ -55,7 +45,7 @@ def main():
     out = {}
     dev = torch.device("cuda", 0)
     need = int(6.5e9 * 6.3 * max(a.lam, 0.1) / 3.75 + 3e9) + HT + a.reads * (synth_gpu.FASTQ_RECORD + 40)
-    d = pick_dir(need, a.dir)
+    d = synth_gpu.pick_dir(need, a.dir)
     if d is None:
         print("no directory with %.0f GB free: nothing measured" % (need / 1e9))
         return 2
@@ -148,49 +138,17 @@ def run(a, out, dev, work):
     t0 = time.time()
     truth = synth_gpu.write_fastq(fq, genomes, a.reads, seed=91).numpy()
     print("FASTQ: %d reads, %.2f GB, generated + written in %.1f s" % (a.reads, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
-    with open(os.path.join(work, "targets.txt"), "w") as f:
-        f.write("".join("%s/g%04d.fa\tT%04d\n" % (work, i, i) for i in range(T)))
-    for i in range(T):          # the driver checks that the target files exist (it builds from them when the database is missing)
-        with open("%s/g%04d.fa" % (work, i), "w") as f:
-            f.write(">g%04d\n" % i)
     del genomes
     torch.cuda.empty_cache()
     exe = os.path.join(ROOT, "bin", "cuCLARK")
     runs = []
     for rep in range(2):
-        t0 = time.time()
-        r = subprocess.run([exe, "-k", str(K), "-T", os.path.join(work, "targets.txt"), "-D", work, "-O", fq, "-R", os.path.join(work, "res"),
-                            "-n", str(a.threads), "-b", str(a.batches), "--verbose"], capture_output=True, text=True)
-        wall = time.time() - t0
-        if r.returncode != 0:
-            print(r.stderr[-3000:])
-            raise SystemExit("cuCLARK failed")
-        done = [l for l in r.stderr.split("\n") if "Done in" in l]
-        timing = [l for l in r.stderr.split("\n") if "timing" in l]
-        # "Done in 0.6s (3870967741 reads/min, 40000000 reads)": the seconds have one decimal, the rate is exact
-        rpm = float(done[0].split("(")[1].split(" reads/min")[0]) if done else float("nan")
-        secs = a.reads / (rpm / 60.0) if rpm == rpm and rpm > 0 else float("nan")
-        runs.append({"done_in_s": round(secs, 4), "Mreads_per_s": round(rpm / 60e6, 2), "wall_s": round(wall, 2),
-                     "line": done[0].strip() if done else "", "timing": timing})
-        print("run %d: wall %.1f s | %s | %s" % (rep, wall, done[0].strip() if done else "?", " | ".join(timing)), flush=True)
-    # the CSV: one line per read, planted reads assigned to their genome
-    csv = os.path.join(work, "res.csv")
-    n_lines = 0
-    good = bad = 0
-    with open(csv, "rb") as f:
-        f.readline()
-        for i, ln in enumerate(f):
-            n_lines += 1
-            if i < 200_000:
-                c = ln.split(b",")
-                assert c[0] == b"r%010d" % i, ln
-                good += c[-3] == b"T%04d" % truth[i]
-                bad += c[-3] != b"T%04d" % truth[i] and c[-3] != b"NA"
-    assert n_lines == a.reads and good > 199_000 and bad < 200, (n_lines, good, bad)
-    best = min(x["done_in_s"] for x in runs)
-    out["e2e_host"] = {"reads": a.reads, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "threads": a.threads, "batches": a.batches,
-                       "runs": runs, "Mreads_per_s": round(a.reads / best / 1e6, 2) if best == best and best > 0 else None,
-                       "csv_lines": n_lines, "first_200k_assigned_to_their_genome": good,
+        r = synth_gpu.host_driver_run(exe, work, K, T, fq, a.reads, threads=a.threads, batches=a.batches, truth=truth)
+        assert r["csv_lines"] == a.reads and r["assigned_to_their_genome"] > 0.995 * r["checked"] and r["assigned_elsewhere"] < 200, r
+        runs.append(r)
+        print("run %d: wall %.1f s | %s | %s" % (rep, r["wall_s"], r["line"], " | ".join(r["timing"])), flush=True)
+    out["e2e_host"] = {"reads": a.reads, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "runs": runs,
+                       "Mreads_per_s": max(x["Mreads_per_s"] for x in runs),
                        "what": "bin/cuCLARK -k 31 -O reads.fq: FASTQ text -> index -> pack -> GPU -> CSV text, the program's own timer "
                                "(the reference's, src/CuCLARK_hh.hh:552-563: the database load is outside it); wall_s = the whole process"}
     print(json.dumps(out), flush=True)
