@@ -290,6 +290,86 @@ inline bool build_database(const Targets &T, unsigned k, unsigned gap, unsigned 
     return true;
 }
 
+// ---- recovery: the database files vanished, the per-target .ht files of an earlier --tsk run are still there --------
+// Reference: getTargetsData (src/CuCLARK_hh.hh:1826-1836) finds "<folder>/<label>_k<k>.ht" for every label and therefore
+// does NOT rebuild from the target files; loadSpecificTargetSets (:633-684) then fails to read the database and -- only
+// when --tsk was given, otherwise "Failed to find the database." -- reads the .ht files back (EHashtable::Load,
+// src/HashTableStorage_hh.hh:513-552: three header lines, then "<k-mer value> <count> ..." per line, kept when
+// count > minCount), sorts every bucket, writes <base>.sz/.ky/.lb and leaves with exit(-1).
+inline bool ht_files_present(const Targets &T, const std::string &folder, unsigned k)
+{
+    for (const std::string &l : T.labels) {
+        char name[4096];
+        std::snprintf(name, sizeof name, "%s/%s_k%lu.ht", folder.c_str(), l.c_str(), (unsigned long)k);
+        if (!file_readable(name)) return false;
+    }
+    return !T.labels.empty();
+}
+
+inline bool recover_database(const Targets &T, const std::string &folder, unsigned k, unsigned min_count, int key_bytes,
+                             const std::string &base, std::string &err)
+{
+    std::fprintf(stderr, "The database will be recovered from saved targets-specific data.\n");
+    struct E { uint64_t r, q; uint16_t t; };
+    std::vector<E> all;
+    for (size_t t = 0; t < T.labels.size(); t++) {
+        char name[4096];
+        // the names --tsk writes (createTargetFilesNames, :342-378)
+        std::snprintf(name, sizeof name, LIGHT ? "%s/%s_k%lu_light.ht" : "%s/%s_k%lu.ht", folder.c_str(), T.labels[t].c_str(), (unsigned long)k);
+        FILE *f = std::fopen(name, "r");
+        if (!f) {
+            std::fprintf(stderr, "Failed to open %s\n", name);
+        } else {
+            char *line = nullptr;
+            size_t cap = 0;
+            for (int h = 0; h < 3; h++) if (getline(&line, &cap, f) == -1) break;       // vector size / - / k-mer size: comment lines in practice
+            while (getline(&line, &cap, f) != -1) {
+                const auto e = split_line(line, 2);
+                if (e.size() < 2) continue;
+                const uint64_t v = (uint64_t)std::atoll(e[0].c_str());
+                const uint32_t count = (uint32_t)std::atol(e[1].c_str());
+                if (count > min_count) all.push_back(E{v % HTSIZE, v / HTSIZE, (uint16_t)t});
+            }
+            std::free(line);
+            std::fclose(f);
+        }
+        std::fprintf(stderr, "\rDataset %zu loaded.   ", t + 1);
+    }
+    std::fprintf(stderr, "%zu %u-mers finally loaded. Creating database in disk...\n", all.size(), k);
+    std::stable_sort(all.begin(), all.end(), [](const E &a, const E &b) { return a.r != b.r ? a.r < b.r : a.q < b.q; });
+    size_t max_bucket = 0;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i;
+        while (j < all.size() && all[j].r == all[i].r) j++;
+        max_bucket = std::max(max_bucket, j - i);
+        i = j;
+    }
+    std::fprintf(stderr, "Hashtable sorting done: maximum number of collisions: %zu\n", max_bucket);       // hTable::sortall, hashTable_hh.hh:215
+    if (max_bucket >= 256) { err = "This table can not be stored on disk: Some bucket list size exceeds 255."; return false; }
+    FILE *fs = std::fopen((base + ".sz").c_str(), "wb");
+    FILE *fk = std::fopen((base + ".ky").c_str(), "wb");
+    FILE *fl = std::fopen((base + ".lb").c_str(), "wb");
+    if (!fs || !fk || !fl) { err = "Failed to create " + base + ".*"; return false; }
+    const uint64_t CH = 1ull << 22;
+    std::vector<uint8_t> szbuf(CH);
+    size_t i = 0;
+    for (uint64_t b0 = 0; b0 < HTSIZE; b0 += CH) {
+        const uint64_t b1 = std::min<uint64_t>(HTSIZE, b0 + CH);
+        std::fill(szbuf.begin(), szbuf.end(), 0);
+        for (; i < all.size() && all[i].r < b1; i++) {
+            szbuf[all[i].r - b0]++;
+            if (key_bytes == 2) { uint16_t v = (uint16_t)all[i].q; std::fwrite(&v, 2, 1, fk); }
+            else if (key_bytes == 4) { uint32_t v = (uint32_t)all[i].q; std::fwrite(&v, 4, 1, fk); }
+            else std::fwrite(&all[i].q, 8, 1, fk);
+            std::fwrite(&all[i].t, 2, 1, fl);
+        }
+        std::fwrite(szbuf.data(), 1, b1 - b0, fs);
+    }
+    std::fclose(fs); std::fclose(fk); std::fclose(fl);
+    std::fprintf(stderr, "Central Hashtable successfully stored in disk.\n");
+    return true;
+}
+
 // GPU build (include/mc_build.h): the host only extracts the k-mers, twice; counting,
 // scatter, per-bucket sort, the one-target rule and compaction run on the device.
 // Same files as build_database(), byte for byte (tests/test_host_cli.py).

@@ -159,6 +159,15 @@ struct Classifier {
         const bool present = file_readable((dbbase + ".sz").c_str()) && file_readable((dbbase + ".ky").c_str()) &&
                              file_readable((dbbase + ".lb").c_str());
         if (present) return;
+        if (ht_files_present(T, folder, (unsigned)opt.k)) {
+            // The per-target .ht files of an earlier --tsk run are all there: the reference does not rebuild from the target
+            // files then (getTargetsData, src/CuCLARK_hh.hh:1826-1836); its load fails, and it either gives up or -- with
+            // --tsk -- puts the database back together from those files and leaves (:633-684, exit(-1)).
+            if (!opt.tsk) die("Failed to find the database.", -1);
+            std::string err;
+            if (!recover_database(T, folder, (unsigned)opt.k, opt.minT, key_bytes, dbbase, err)) die(err, -1);
+            std::exit(-1);
+        }
         if (opt.verbose && opt.tsk) std::cerr << "Creation of targets specific k-mers files requested " << std::endl;   // (:1914-1917)
         std::cerr << "Starting the creation of the database of targets specific " << opt.k
                   << "-mers from input files..." << std::endl;

@@ -242,6 +242,38 @@ def test_tsk_writes_the_reference_s_target_specific_kmer_files(tmp_path):
         assert hashlib.sha256(open(base + ext, "rb").read()).hexdigest() == digest, ext
 
 
+def test_tsk_recovery_rebuilds_the_database_from_the_ht_files(tmp_path):
+    """The database files are gone, the per-target .ht files of an earlier --tsk run are still there
+    (src/CuCLARK_hh.hh:633-684): with --tsk the database is put back together from them -- byte-identical to what the
+    REFERENCE's builder wrote for these genomes (tests/golden/tsk/db_sha256.txt) -- and the program leaves with
+    exit(-1), as the reference does; without --tsk it says "Failed to find the database." (the reference does not
+    rebuild from the target files when the .ht files exist, getTargetsData :1826-1836).  Before any device is
+    opened: no GPU needed.  (tests/test_ref_host.py runs the reference's own recovery next to this one.)"""
+    import hashlib
+    import shutil
+    _build()
+    gold = os.path.join(ROOT, "tests", "golden", "tsk")
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    for name in ("T0_k31.ht", "T1_k31.ht", "S9_k31.ht"):
+        shutil.copy(os.path.join(gold, name), str(dbdir / name))
+    args = ["-k", "31", "-T", os.path.join(gold, "targets.txt"), "-D", str(dbdir) + "/", "-O", os.path.join(gold, "g0.fa"),
+            "-R", str(tmp_path / "res")]
+    base = str(dbdir / "db_central_k31_t3_s1610612741_m0.tsk")
+    r = subprocess.run([os.path.join(BIN, "cuCLARK")] + args, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 255 and "Failed to find the database." in r.stderr and not os.path.exists(base + ".ky")
+    r = subprocess.run([os.path.join(BIN, "cuCLARK")] + args + ["--tsk"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 255, r.stderr
+    for msg in ("The database will be recovered from saved targets-specific data.", "Dataset 3 loaded.",
+                "31-mers finally loaded. Creating database in disk...", "Central Hashtable successfully stored in disk."):
+        assert msg in r.stderr, (msg, r.stderr)
+    want = dict(l.split()[::-1] for l in open(os.path.join(gold, "db_sha256.txt")))
+    for ext, digest in want.items():
+        assert hashlib.sha256(open(base + ext, "rb").read()).hexdigest() == digest, ext
+    n_kmers = sum(1 for name in ("T0_k31.ht", "T1_k31.ht", "S9_k31.ht") for ln in open(os.path.join(gold, name)) if not ln.startswith("#"))
+    assert ("%d 31-mers finally loaded." % n_kmers) in r.stderr and os.path.getsize(base + ".ky") == 4 * n_kmers
+
+
 def test_cli_errors_match_reference_messages(tmp_path):
     _build()
     r = _run("cuCLARK", ["-k", "40", "-T", "x", "-D", "y", "-O", "z", "-R", "w"])

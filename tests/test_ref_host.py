@@ -104,3 +104,34 @@ def test_reference_host_and_our_host_agree_byte_for_byte(tmp_path, mode):
     assert our_csv == ref_csv
     assigned = sum(1 for ln in ref_csv.split("\n")[1:-1] if ",NA," not in ln)
     assert assigned > 500
+
+
+def test_reference_recovery_from_ht_files_and_ours_write_the_same_database(tmp_path):
+    """--tsk with the database files gone and the per-target .ht files still there: the REFERENCE's host driver
+    (full variant, oracle/_ref/ref_host_mc_full) puts the database back together with its own code
+    (loadSpecificTargetSets, src/CuCLARK_hh.hh:633-684: EHashtable::Load + SortAllHashTable + Write) and leaves with
+    exit(-1); bin/cuCLARK does the same.  The three files must be byte-identical, and equal to what the reference's
+    builder wrote for these genomes in the first place (tests/golden/tsk/db_sha256.txt)."""
+    import hashlib
+    import shutil
+    ref_full = os.path.join(ROOT, "oracle", "_ref", "ref_host_mc_full")
+    ours_full = os.path.join(ROOT, "bin", "cuCLARK")
+    if not os.path.exists(ref_full):
+        pytest.skip("oracle/_ref/ref_host_mc_full not built (needs /root/reference at build time)")
+    gold = os.path.join(ROOT, "tests", "golden", "tsk")
+    digests = {}
+    for tag, exe in (("ref", ref_full), ("ours", ours_full)):
+        d = tmp_path / ("db_" + tag)
+        d.mkdir()
+        for name in ("T0_k31.ht", "T1_k31.ht", "S9_k31.ht"):
+            shutil.copy(os.path.join(gold, name), str(d / name))
+        r = subprocess.run([exe, "-k", "31", "-T", os.path.join(gold, "targets.txt"), "-D", str(d) + "/", "-O", os.path.join(gold, "g0.fa"),
+                            "-R", str(tmp_path / ("res_" + tag)), "--tsk"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 255, (tag, r.stderr[-1500:])
+        assert "The database will be recovered from saved targets-specific data." in r.stderr, (tag, r.stderr[-1500:])
+        assert "Central Hashtable successfully stored in disk." in r.stderr, (tag, r.stderr[-1500:])
+        base = str(d / "db_central_k31_t3_s1610612741_m0.tsk")
+        digests[tag] = {ext: hashlib.sha256(open(base + ext, "rb").read()).hexdigest() for ext in (".sz", ".ky", ".lb")}
+    assert digests["ref"] == digests["ours"]
+    want = dict(l.split()[::-1] for l in open(os.path.join(gold, "db_sha256.txt")))
+    assert digests["ours"] == want
