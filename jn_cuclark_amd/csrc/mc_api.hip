@@ -376,7 +376,7 @@ int index_end(mc_ctx *c)
     }
     index_abort(c);         // releases the counters
     int occ = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mc::mz::mz_query_kernel<mc::mz::MZ_ALL>, mc::BLOCK_THREADS, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (mc::mz::mz_query_kernel<mc::mz::MZ_ALL, 0>), mc::BLOCK_THREADS, 0));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
     if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
@@ -586,11 +586,19 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
         m.inv_htsize = fp_ok ? 1.0 / (double)c->htsize : 0.0;
         const int shard = c->info.n_parts > 1 ? mc::mz::MZ_LINES
                         : (c->info.shard_begin != 0 || c->info.shard_end != c->htsize) ? mc::mz::MZ_BUCKETS : mc::mz::MZ_ALL;
+        // k = 31 (cuCLARK's default) and k = 27 (cuCLARK-l) have kernels with the k-mer length compiled in
+#define MC_MZ_LAUNCH(SH)                                                                                                   \
+        do {                                                                                                               \
+            if (c->k == 31u && c->mz_m == mc::mz::mmer_len(31u)) hipLaunchKernelGGL((mc::mz::mz_query_kernel<SH, 31>), g, b, 0, st, m);      \
+            else if (c->k == 27u && c->mz_m == mc::mz::mmer_len(27u)) hipLaunchKernelGGL((mc::mz::mz_query_kernel<SH, 27>), g, b, 0, st, m); \
+            else hipLaunchKernelGGL((mc::mz::mz_query_kernel<SH, 0>), g, b, 0, st, m);                                     \
+        } while (0)
         switch (shard) {
-        case mc::mz::MZ_LINES:   hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_LINES>, g, b, 0, st, m); break;
-        case mc::mz::MZ_BUCKETS: hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_BUCKETS>, g, b, 0, st, m); break;
-        default:                 hipLaunchKernelGGL(mc::mz::mz_query_kernel<mc::mz::MZ_ALL>, g, b, 0, st, m); break;
+        case mc::mz::MZ_LINES:   MC_MZ_LAUNCH(mc::mz::MZ_LINES); break;
+        case mc::mz::MZ_BUCKETS: MC_MZ_LAUNCH(mc::mz::MZ_BUCKETS); break;
+        default:                 MC_MZ_LAUNCH(mc::mz::MZ_ALL); break;
         }
+#undef MC_MZ_LAUNCH
     } else if (!c->wide) {
         if (c->info.line_bytes == 64) hipLaunchKernelGGL((mc::query_kernel<64, false>), g, b, 0, st, a);
         else                          hipLaunchKernelGGL((mc::query_kernel<128, false>), g, b, 0, st, a);

@@ -696,7 +696,11 @@ static constexpr int MZ_LDS_WAVE = MZ_LDS_RDPTR + ((GROUP_READS + 1) * 4 + 15) /
 static_assert(MZ_LDS_LINES % 16 == 0 && MZ_LDS_WAVE % 16 == 0, "16-byte aligned LDS regions");
 // SHARD: MZ_ALL / MZ_BUCKETS / MZ_LINES (separate instantiations keep the divider and the ranges
 // out of the unsharded kernel's scalar registers).
-template <int SHARD>
+// KC: the k-mer length as a compile-time constant (31: cuCLARK's default, 27: cuCLARK-l), 0 = read from the
+// arguments.  With a run-time k the shift amounts, masks and "k < 32" / "k >= 17" switches derived from it were kept
+// in scalar registers the kernel does not have: a dozen of them were reloaded from spill lanes (v_readlane) at the
+// start of every step.  As constants they are immediates and the switches disappear.
+template <int SHARD, int KC>
 __global__ __launch_bounds__(BLOCK_THREADS, MC_MZ_MIN_WAVES)
 void mz_query_kernel(const MzArgs A)
 {
@@ -712,7 +716,7 @@ void mz_query_kernel(const MzArgs A)
     uint64_t *keyv = reinterpret_cast<uint64_t *>(linebuf);     // aliases the parked lines (see above)
     uint32_t *rdptr = reinterpret_cast<uint32_t *>(s_mem[wave] + MZ_LDS_RDPTR);
 
-    const uint32_t k = a.k, m = A.m;
+    const uint32_t k = KC ? (uint32_t)KC : a.k, m = KC ? mmer_len((uint32_t)KC) : A.m;
     constexpr uint32_t W = MZ_MAXW;            // k - m + 1 windows: m = k - (MZ_MAXW - 1) (mmer_len)
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
@@ -724,7 +728,23 @@ void mz_query_kernel(const MzArgs A)
     // wave-uniform switches are tested where they are used, from ONE scalar register (hoisted out of the
     // loops they become lane masks that live in -- and are spilled from -- two registers each)
     auto flags_now = [&]() -> uint32_t { uint32_t f = a.flags; asm volatile("" : "+s"(f)); return f; };
-    const uint32_t row_len = 2u * a.maxhits + 2u;
+    // Arguments that are needed once per read or less are read from the kernel-argument segment where they are used
+    // (a scalar load from constant memory) instead of living in scalar registers through every loop: the kernel has
+    // more wave-uniform values than registers for them, and what does not fit is parked in lanes of a vector
+    // register and fetched back with v_readlane in the hot loops (loop counters among them).
+    auto karg = [&](size_t off, auto type_c) {
+        typedef decltype(type_c) T;
+        const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(off));           // not hoisted, not merged with the loads at the kernel's start
+        return *reinterpret_cast<const __attribute__((address_space(4))) T *>(p + off);
+    };
+    auto arg_maxhits = [&]() { return karg(offsetof(MzArgs, q) + offsetof(QueryArgs, maxhits), uint32_t()); };
+    auto arg_sparse_rows = [&]() { return karg(offsetof(MzArgs, q) + offsetof(QueryArgs, sparse_rows), (uint16_t *)nullptr); };
+    auto arg_final_rows = [&]() { return karg(offsetof(MzArgs, q) + offsetof(QueryArgs, final_rows), (uint16_t *)nullptr); };
+    auto arg_over_maxhits = [&]() { return karg(offsetof(MzArgs, q) + offsetof(QueryArgs, over_maxhits), (unsigned long long *)nullptr); };
+    auto arg_extra = [&]() { return karg(offsetof(MzArgs, extra), (const uint8_t *)nullptr); };
+    auto arg_reads_ptr = [&]() { return karg(offsetof(MzArgs, q) + offsetof(QueryArgs, reads_ptr), (const uint32_t *)nullptr); };
+    auto arg_containers = [&]() { return karg(offsetof(MzArgs, q) + offsetof(QueryArgs, containers), (const uint16_t *)nullptr); };
 
     for (uint32_t g = blockIdx.x * WAVES_PER_BLOCK + wave; g < n_groups; g += gstride) {
         const uint32_t r0 = g * GROUP_READS;
@@ -732,7 +752,7 @@ void mz_query_kernel(const MzArgs A)
         uint32_t ptr_v = 0;
         {
             const uint32_t lg = opaque(lane);
-            if (lg <= nr) { ptr_v = a.reads_ptr[r0 + lg]; rdptr[lg] = ptr_v; }
+            if (lg <= nr) { ptr_v = arg_reads_ptr()[r0 + lg]; rdptr[lg] = ptr_v; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -747,19 +767,20 @@ void mz_query_kernel(const MzArgs A)
         const uint32_t re = staged ? (uint32_t)(63 - __builtin_clzll((unsigned long long)fits)) : rs + 1u;
         const uint32_t c1 = lane_bcast(ptr_v, re);
         if (staged) {
+            const uint16_t *containers = arg_containers();
             for (uint32_t j = opaque(lane) * 8u; c0a + j < c1; j += 64u * 8u) {
                 const uint64_t gi = (uint64_t)c0a + j;
                 // the slice holds the containers as big-endian 64-bit words (4 containers each,
                 // first base in the top bits): container i lives at u16 index i ^ 3, and any
                 // k-mer is cut from two consecutive aligned words
                 if (gi + 8u <= (uint64_t)n_con) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(a.containers + gi);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(containers + gi);
                     *reinterpret_cast<uint4 *>(slice + j) =
                         make_uint4(__builtin_rotateright32(v.y, 16), __builtin_rotateright32(v.x, 16),
                                    __builtin_rotateright32(v.w, 16), __builtin_rotateright32(v.z, 16));
                 } else {
                     for (uint32_t t = 0; t < 8u; t++)
-                        slice[(j + t) ^ 3u] = (gi + t < (uint64_t)n_con) ? a.containers[gi + t] : (uint16_t)0;
+                        slice[(j + t) ^ 3u] = (gi + t < (uint64_t)n_con) ? containers[gi + t] : (uint16_t)0;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -773,7 +794,7 @@ void mz_query_kernel(const MzArgs A)
                 return slice[(li < (uint32_t)(MZ_STAGE_CON + 12) ? li : (uint32_t)(MZ_STAGE_CON + 12)) ^ 3u];
             } else {
                 const uint32_t ii = i < n_con ? i : n_con - 1u;
-                return a.containers[ii];
+                return arg_containers()[ii];
             }
         };
         // `len` bases starting at base position p of the part whose containers start at `first`
@@ -1133,7 +1154,7 @@ void mz_query_kernel(const MzArgs A)
                                     }
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
-                                    fetch_lines(A.extra, n - ch < (uint32_t)MZ_RUNS ? n - ch : (uint32_t)MZ_RUNS, std::false_type{});
+                                    fetch_lines(arg_extra(), n - ch < (uint32_t)MZ_RUNS ? n - ch : (uint32_t)MZ_RUNS, std::false_type{});
 #pragma unroll
                                     for (int s = 0; s < MZ_NS; s++) {
                                         if (here[s] == 0) continue;
@@ -1212,20 +1233,21 @@ void mz_query_kernel(const MzArgs A)
             const uint64_t rd = (uint64_t)(r0 + ri);
             bool valid = lane < n_acc;
             uint32_t rank = 0;
-            const bool need_rank = (flags_now() & 2u) || (n_acc > a.maxhits);
+            const uint32_t maxhits = arg_maxhits(), row_len = 2u * maxhits + 2u;
+            const bool need_rank = (flags_now() & 2u) || (n_acc > maxhits);
             if (need_rank) {
                 for (uint32_t j = 0; j < n_acc; j++) {
                     const uint32_t tj = lane_bcast(acc_t, j);
                     rank += (tj < acc_t) ? 1u : 0u;
                 }
-                if (n_acc > a.maxhits) {
-                    valid = valid && rank < a.maxhits;
-                    if (__builtin_amdgcn_inverse_ballot_w64(1ull)) atomicAdd(a.over_maxhits, 1ull);      // lane 0
+                if (n_acc > maxhits) {
+                    valid = valid && rank < maxhits;
+                    if (__builtin_amdgcn_inverse_ballot_w64(1ull)) atomicAdd(arg_over_maxhits(), 1ull);      // lane 0
                 }
             }
-            const uint32_t n_keep = n_acc > a.maxhits ? a.maxhits : n_acc;
+            const uint32_t n_keep = n_acc > maxhits ? maxhits : n_acc;
             if (flags_now() & 2u) {
-                uint16_t *row = a.sparse_rows + rd * row_len;
+                uint16_t *row = arg_sparse_rows() + rd * row_len;
                 if (__builtin_amdgcn_inverse_ballot_w64(1ull)) row[0] = (uint16_t)n_keep;           // lane 0
                 if (valid) { row[1 + 2 * rank] = (uint16_t)acc_t; row[2 + 2 * rank] = (uint16_t)sat_u16(acc_c); }
                 for (uint32_t i = 1u + 2u * n_keep + lane; i < row_len; i += 64u) row[i] = 0;
@@ -1256,7 +1278,7 @@ void mz_query_kernel(const MzArgs A)
                 // 2-byte aligned address; global memory takes unaligned stores) instead of one select chain per lane
                 if (__builtin_amdgcn_inverse_ballot_w64(1ull)) {
                     struct __attribute__((packed, aligned(2))) Row5 { uint32_t w0, w1; uint16_t h; };
-                    *reinterpret_cast<Row5 *>(a.final_rows + rd * 5u) =
+                    *reinterpret_cast<Row5 *>(arg_final_rows() + rd * 5u) =
                         Row5{(o0 & 0xFFFFu) | (o1 << 16), (o2 & 0xFFFFu) | (o3 << 16), (uint16_t)o4};
                 }
             }

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../jn_cuclark_amd/csrc"
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function --offload-device-only "$@" -c mc_api.hip -o $T/dev.o
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/dev.o --targets=hip-amdgcn-amd-amdhsa--gfx950 --output=$T/dev.elf
-K=${KERNEL:-_ZN2mc2mz15mz_query_kernelILi0EEEvNS0_6MzArgsE}
+K=${KERNEL:-_ZN2mc2mz15mz_query_kernelILi0ELi31EEEvNS0_6MzArgsE}
 /opt/rocm/lib/llvm/bin/llvm-objdump -d --disassemble-symbols=$K $T/dev.elf > $T/k.s
 python3 - $T/k.s <<'PY'
 import re, sys, collections
