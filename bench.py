@@ -267,7 +267,9 @@ def main():
         hr = 0.0 if hit_rate != hit_rate else hit_rate
         bytes_per_read = 54.0 + kmers_per_read * (8.0 + 4.0 * nonempty + 2.0 * hr)
         achieved = bytes_per_read * n_reads / (kern_ms_avg * 1e-3) / 1e9
-        kernel_name = ("mc::mz::mz_query_kernel<%d>" % (2 if shard_mode else 0)) if index == "minimizer" else "mc::query_kernel<%d, false>" % info["line_bytes"]
+        # (the k-mer length is compiled in for k = 31 and 27, csrc/mc_minimizer.hpp)
+        kernel_name = ("mc::mz::mz_query_kernel<%d, %d>" % (2 if shard_mode else 0, k if k in (31, 27) else 0)) if index == "minimizer" \
+            else "mc::query_kernel<%d, false>" % info["line_bytes"]
         # HBM traffic per launch comes from a rocprofv3 --pmc run of this same command (tools/prof_pmc.sh writes
         # profiles/traffic.json): counters cannot be read from inside the process.  The figure is used only if it
         # was taken with the SAME kernel sources on the same workload; otherwise null.

@@ -5,7 +5,7 @@ cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 ARGS="$1"; shift
 for lib in "$@"; do
   O=gpurun_out/pmcq_$(basename $lib .so); rm -rf $O; mkdir -p $O
-  MC_LIB_PATH=$PWD/$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O -- python3 bench.py --no-cpu-baseline --no-pipelined --verify 0 --steps 3 --warmup 1 $ARGS > $O/bench.json 2> $O/err.txt
+  MC_LIB_PATH=$PWD/$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O -- python3 bench.py --no-cpu-baseline --no-pipelined --no-extras --verify 0 --steps 3 --warmup 1 $ARGS > $O/bench.json 2> $O/err.txt
   f=$(find $O -name "*counter_collection.csv" | head -1)
   echo "== $lib $(python3 -c "import json;j=json.loads(open('$O/bench.json').readlines()[-1]);print(j['value'], j['roofline']['kernel_ms'])" 2>/dev/null)"
   python3 - "$f" <<'PY'

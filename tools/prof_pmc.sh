@@ -6,7 +6,7 @@ set -u
 TAG=${1:-pmc}; shift || true
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--steps ${PROF_STEPS:-3} --warmup ${PROF_WARMUP:-1} --no-cpu-baseline --no-pipelined --verify 0 $*"
+ARGS="--steps ${PROF_STEPS:-3} --warmup ${PROF_WARMUP:-1} --no-cpu-baseline --no-pipelined --no-extras --verify 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 { head -1 $f; grep "query_kernel" $f; } > $OUT/kernel_stats_query.csv
