@@ -30,6 +30,9 @@ ap.add_argument("--sample", type=int, default=2000)
 ap.add_argument("--bg-reads", type=int, default=500, help="extra reads planted around background k-mers of the table")
 ap.add_argument("--targets", type=int, default=8192)
 ap.add_argument("--ranges", type=int, default=32)
+ap.add_argument("--pairs", action="store_true",
+                help="configs[4]: 2 x 250 bp pairs (one read of two parts, src/file.cc:250) instead of 150 bp reads: mate 1 a window of "
+                     "a genome, mate 2 the reverse complement of the window 400 bases on, both with 1 %% substitutions")
 ap.add_argument("--only-parts", type=str, default="", help="comma list: build and time only these parts (no merge check)")
 a = ap.parse_args()
 
@@ -57,7 +60,36 @@ def chunks():
 
 
 n_mix = a.reads
-rp, con, truth = synth_gpu.make_reads(genomes, n_mix, 150, seed=42, return_truth=True)
+PER_READ = 20           # u16 words of a packed read: [150][19 containers]
+KMERS = 120
+if a.pairs:
+    a.bg_reads = 0
+    PER_READ, KMERS = 2 * 33, 2 * 220
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    npl = n_mix // 2
+    gi = torch.randint(0, a.targets, (npl,), device=dev, generator=g)
+    pos = torch.randint(0, GLEN - 700, (npl,), device=dev, generator=g)
+    ar = torch.arange(250, device=dev, dtype=torch.int64)[None, :]
+    flat = genomes.reshape(-1)
+    codes = torch.randint(0, 4, (n_mix, 2, 250), dtype=torch.uint8, device=dev, generator=g)
+    m1 = flat[(gi * GLEN + pos)[:, None] + ar]
+    m2 = 3 - flat[(gi * GLEN + pos + 400)[:, None] + ar].flip(1)                   # the other strand
+    for j, w in enumerate((m1, m2)):
+        mut = torch.rand((npl, 250), device=dev, generator=g) < 0.01
+        delta = torch.randint(1, 4, (npl, 250), dtype=torch.uint8, device=dev, generator=g)
+        codes[:npl, j] = torch.where(mut, (w + delta) & 3, w)
+    pad = torch.zeros((n_mix, 2, 256), dtype=torch.int32, device=dev)
+    pad[:, :, :250] = codes
+    sh = (14 - 2 * torch.arange(8, device=dev, dtype=torch.int32))[None, None, None, :]
+    cw = (pad.reshape(n_mix, 2, 32, 8) << sh).sum(dim=3)
+    out = torch.empty((n_mix, 2, 33), dtype=torch.int16, device=dev)
+    out[:, :, 0] = 250
+    out[:, :, 1:] = cw.to(torch.int16)
+    rp, con, truth = None, out.reshape(-1), gi
+    codes_all = codes
+else:
+    rp, con, truth = synth_gpu.make_reads(genomes, n_mix, 150, seed=42, return_truth=True)
 # + reads around BACKGROUND k-mers of the table (a uniform random read never hits one of 32e9 out of 4^31): a stored
 # k-mer from the generator's CPU twin, where its stored value is the canonical form, inside 150 random bases
 rng = np.random.default_rng(7)
@@ -76,10 +108,11 @@ for i in range(a.bg_reads):
     kc = np.array([(int(c) >> (2 * (K - 1 - j))) & 3 for j in range(K)], dtype=np.uint8)
     bg_codes[i, at:at + K] = kc if rng.integers(0, 2) else (3 - kc[::-1])       # either strand
     n_planted_bg += 1
-_, con_bg = synth.pack_uniform(bg_codes)
-con = torch.cat([con, torch.from_numpy(con_bg.view(np.int16)).to(dev)])
+if a.bg_reads:
+    _, con_bg = synth.pack_uniform(bg_codes)
+    con = torch.cat([con, torch.from_numpy(con_bg.view(np.int16)).to(dev)])
 n = n_mix + a.bg_reads
-rp = (torch.arange(n + 1, device=dev, dtype=torch.int64) * 20).to(torch.int32)
+rp = (torch.arange(n + 1, device=dev, dtype=torch.int64) * PER_READ).to(torch.int32)
 rp2, con2 = synth_gpu.make_reads(genomes, a.rate_reads, 150, seed=43)
 st = torch.cuda.current_stream().cuda_stream
 row_len = 2 * MAXHITS + 2
@@ -135,28 +168,32 @@ tr = truth.cpu().numpy()
 ok = fin[:npl, 1] == tr + 1
 assert ok.mean() > 0.995, ok.mean()
 assert (fin[:npl, 1][~ok] != 0).mean() < 0.01 if (~ok).any() else True
-assert 0.60 < fin[:npl, 0].mean() / 120 < 0.85
-assert np.all(fin[:, 0] <= 120) and np.all(fin[:, 2] <= fin[:, 0]) and np.all(fin[:, 4] <= fin[:, 2])
+assert 0.60 < fin[:npl, 0].mean() / KMERS < 0.85
+assert np.all(fin[:, 0] <= KMERS) and np.all(fin[:, 2] <= fin[:, 0]) and np.all(fin[:, 4] <= fin[:, 2])
 rnd_hits = int(fin[npl:n_mix, 0].astype(np.int64).sum())
 bg_hit = int((fin[n_mix:, 0] >= 1).sum())
 assert bg_hit == a.bg_reads, "a read planted around a stored background k-mer found nothing"
-print("ground truth: %d genome-sampled reads, %.4f assigned to their genome, mean hits %.1f of 120; %d random reads with %d hits in all; "
+print("ground truth: %d genome-sampled reads, %.4f assigned to their genome, mean hits %.1f of %d; %d random reads with %d hits in all; "
       "%d of %d reads around a stored background k-mer hit"
-      % (npl, ok.mean(), fin[:npl, 0].mean(), n_mix - npl, rnd_hits, bg_hit, a.bg_reads), flush=True)
+      % (npl, ok.mean(), fin[:npl, 0].mean(), KMERS, n_mix - npl, rnd_hits, bg_hit, a.bg_reads), flush=True)
 
 # ---- exact, on a sample: a numpy model of the table ------------------------------------------------------------
 m = a.sample // 2
 idx = np.concatenate([np.arange(m), np.arange(n_mix - m, n_mix), np.arange(n_mix, n)])
-con_h = con.cpu().numpy().view(np.uint16).reshape(n, -1)[idx]
-codes = np.zeros((idx.size, 152), dtype=np.uint8)
-for j in range(8):
-    codes[:, j::8][:, :19] = ((con_h[:, 1:] >> (14 - 2 * j)) & 3).astype(np.uint8)
-codes = codes[:, :150]
+if a.pairs:
+    parts_of = [[codes_all[int(i), 0].cpu().numpy(), codes_all[int(i), 1].cpu().numpy()] for i in idx]
+else:
+    con_h = con.cpu().numpy().view(np.uint16).reshape(n, -1)[idx]
+    codes = np.zeros((idx.size, 152), dtype=np.uint8)
+    for j in range(8):
+        codes[:, j::8][:, :19] = ((con_h[:, 1:] >> (14 - 2 * j)) & 3).astype(np.uint8)
+    codes = codes[:, :150]
+    parts_of = [[codes[i]] for i in range(idx.size)]
 g_r, g_q, g_l = app
 expected = np.zeros((idx.size, 5), dtype=np.uint16)
 n_bg = n_gen = 0
 for i in range(idx.size):
-    c = synth.canonical(synth.kmers_of(codes[i], K), K)
+    c = np.concatenate([synth.canonical(synth.kmers_of(pc, K), K) for pc in parts_of[i]])
     r, q = c % np.uint64(HT), c // np.uint64(HT)
     labs = []
     # genome k-mers: the sorted (r, q) list on the device
@@ -186,5 +223,5 @@ for i in range(idx.size):
             expected[i, 3], expected[i, 4] = t[s2] + 1, rest[s2]
 assert np.array_equal(expected, fin[idx]), "merged result differs from the numpy model of the table"
 print("exact: %d reads (%d k-mers looked up in a numpy model of the table: %d background hits, %d genome hits) == merged result of the %d parts, row for row"
-      % (idx.size, idx.size * 120, n_bg, n_gen, a.parts), flush=True)
+      % (idx.size, idx.size * KMERS, n_bg, n_gen, a.parts), flush=True)
 print("done in %.0f s" % (time.time() - t_all), flush=True)
