@@ -488,6 +488,15 @@ def extra_genomes(args, torch, np, dev, dev_index, _genomes):
                          "lines_crowded": info["n_lines_crowded"], "largest_line_kmers": info["largest_line"], "hbm_bytes": info["device_bytes"]},
                "what": "the same kernel, 10 M x 150 bp per launch, on a table whose EVERY k-mer comes from structured genomes "
                        "(4096 x 1.5 Mb: genera of 4 with shared sequence, a conserved block, tandem repeats, poly-A)"}
+        # HBM traffic per launch of THIS table, from its own rocprofv3 --pmc passes, if they were taken with these sources
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_genomes.json")))
+            if (tj.get("source_sha") == source_sha() and tj.get("reads_per_launch") == n_reads and tj.get("htsize") == ht
+                    and tj.get("kmers_per_line") == res["index"]["kmers_per_line"]):
+                res["traffic"] = tj.get("hbm_bytes_per_launch")
+                res["hbm_traffic_GBs"] = round(tj["hbm_bytes_per_launch"] / (kern * 1e-3) / 1e9, 1)
+        except Exception:
+            pass
         if args.verify:
             from oracle import pyoracle
             fin = fin_t.cpu().numpy().view(np.uint16)
