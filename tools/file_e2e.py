@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--lam", type=float, default=LAM)
     ap.add_argument("--json", default=None)
     ap.add_argument("--skip-load-compare", action="store_true")
+    ap.add_argument("--sweep", default="", help="threads:batches pairs to run after the two standard runs, e.g. 16:64,16:128,32:64")
     ap.add_argument("--load-times", action="store_true",
                     help="also time tools/load_time.py on the files: 1 member, 2 and 3 members (parts) on this card, with this "
                          "build and -- when build/libmcclark_r02.so is there -- with round 2's loader")
@@ -147,6 +148,11 @@ def run(a, out, dev, work):
         assert r["csv_lines"] == a.reads and r["assigned_to_their_genome"] > 0.995 * r["checked"] and r["assigned_elsewhere"] < 200, r
         runs.append(r)
         print("run %d: wall %.1f s | %s | %s" % (rep, r["wall_s"], r["line"], " | ".join(r["timing"])), flush=True)
+    for tb in [x for x in a.sweep.split(",") if x]:
+        t_, b_ = (int(v) for v in tb.split(":"))
+        r = synth_gpu.host_driver_run(exe, work, K, T, fq, a.reads, threads=t_, batches=b_, truth=truth)
+        print("sweep -n %d -b %d: %.2f Mreads/s, wall %.1f s | %s" % (t_, b_, r["Mreads_per_s"], r["wall_s"], " | ".join(r["timing"])), flush=True)
+        out.setdefault("sweep", []).append({"threads": t_, "batches": b_, "Mreads_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"]})
     out["e2e_host"] = {"reads": a.reads, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "runs": runs,
                        "Mreads_per_s": max(x["Mreads_per_s"] for x in runs),
                        "what": "bin/cuCLARK -k 31 -O reads.fq: FASTQ text -> index -> pack -> GPU -> CSV text, the program's own timer "
