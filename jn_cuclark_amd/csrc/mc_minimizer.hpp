@@ -16,8 +16,10 @@
 //   line(c) = mulhi(mix32(K(c)), lines per part)      part(c) = mulhi(mix32'(K(c)), n_parts)
 //             (two hashes of the 52-bit key: a table spread over G contexts addresses G x 2^32 lines)
 //   a line  = 128 bytes: 12 keys (full canonical k-mers, u64, ascending, unused = all ones last),
-//             12 labels (u16), dword30 = extra lines (bits 0-2) | spill flag (bit 3) | Bloom word
-//             over the k-mers that are not in the first line (high 16 bits), dword31 = first extra line
+//             12 labels (u16), dword30 = 0, or for a line that overflows: lines per chain (bits 0-1) | "also the
+//             chain behind" (bit 2) | log2 of the number of chains (bits 3-7) | bit 16; dword31 = first extra line.
+//             A line that overflows keeps 11 keys: slot 11 is a 62-bit Bloom word over the k-mers that are not in
+//             the first line
 //   extra lines (same shape, contiguous per line) hold what does not fit: a chain of at most MZ_EMAX
 //   lines.  A CROWDED line (one minimizer shared by thousands of k-mers: a conserved m-mer in many
 //   genomes) gets 2^s such chains ("segments") and a k-mer's segment is picked by a hash of the k-mer
