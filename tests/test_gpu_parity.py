@@ -307,6 +307,30 @@ def test_file_loader_and_sampling(gpu, oracle, tmp_path):
         assert db.read(str(tmp_path / "nope")) is False     # caller rebuilds (CuCLARK_hh.hh:622-684)
 
 
+def test_file_loader_over_several_chunks_with_sampling(gpu, oracle, tmp_path):
+    """cuCLARK-l's table size (57 777 779 buckets = four chunks of the loader's pipeline: reader thread, two pinned
+    buffers, staging sets) with and without the -s sampling rule (CuClarkDB.cu:503-513: the counter runs over the
+    non-empty buckets of the WHOLE table, the unsampled buckets are cut out of every chunk); on both indexes"""
+    k, ht = 27, 57777779
+    genomes = synth.toy_genomes(6, 30000, seed=77, shared=500)
+    sz, ky, lb = synth.genome_db(genomes, k, ht)
+    nzb = np.flatnonzero(sz)
+    assert nzb[0] < (1 << 24) and nzb[-1] > 3 * (1 << 24)            # k-mers in the first and in the last chunk
+    canon = np.repeat(nzb, sz[nzb]).astype(np.uint64) + ky.astype(np.uint64) * np.uint64(ht)
+    base = str(tmp_path / "db_central_k27_t6_s57777779_m0_light_4.tsk")
+    oracle.db_write(base, ht, 4, canon, lb)
+    codes, _ = synth.sample_reads(genomes, 3000, 150, seed=13)
+    rp, con = synth.pack_uniform(codes)
+    from jn_cuclark_amd import CuClarkDB
+    for s_ in (1, 2, 5):
+        want, _ = oracle.OracleDB.load(base, ht, 4, sampling=s_).classify(k, rp, con, 23)
+        with CuClarkDB(k=k, numBatches=1, numTargets=6, device=0, htsize=ht, maxhits=23) as db:
+            assert db.read(base, modCollision=s_) is True
+            got = db.classify(rp, con)
+        assert np.array_equal(got, want), s_
+        assert (want[:, 2] > 0).sum() > (2500 if s_ == 1 else 1500)
+
+
 def test_batched_streaming_interface(gpu, oracle):
     """several batches in flight through malloc/readyBatch/queryBatch/waitForBatch"""
     genomes, sz, ky, lb = small_db()
