@@ -362,7 +362,7 @@ def pick_dir(need_bytes, want=None):
     return None
 
 
-def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches=32, truth=None, check=200_000):
+def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches=32, truth=None, check=200_000, fastq2=None):
     """`exe -k K -T targets -D work -O fastq -R work/res` (the database files must be in `work` under the reference's
     name, src/CuCLARK_hh.hh:586-590): returns the program's own rate ("Done in Xs (N reads/min, M reads)", the
     reference's timer, src/CuCLARK_hh.hh:552-563, :1931-1939: file -> CSV, the database load is outside it), the wall
@@ -378,7 +378,8 @@ def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches
             with open(p, "w") as f:
                 f.write(">g%04d\n" % i)
     t0 = _t.time()
-    r = subprocess.run([exe, "-k", str(k), "-T", os.path.join(work, "targets.txt"), "-D", work, "-O", fastq, "-R", os.path.join(work, "res"),
+    inputs = ["-P", fastq, fastq2] if fastq2 else ["-O", fastq]          # -P: paired-end mates in two files (src/main.cc:43-69)
+    r = subprocess.run([exe, "-k", str(k), "-T", os.path.join(work, "targets.txt"), "-D", work] + inputs + ["-R", os.path.join(work, "res"),
                         "-n", str(threads), "-b", str(batches), "--verbose"], capture_output=True, text=True)
     wall = _t.time() - t0
     if r.returncode != 0:

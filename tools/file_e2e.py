@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--lam", type=float, default=LAM)
     ap.add_argument("--json", default=None)
     ap.add_argument("--skip-load-compare", action="store_true")
+    ap.add_argument("--paired", action="store_true",
+                    help="also: the same reads as mates of two files (-P r_1.fq r_2.fq; mate 2 = the same records again), "
+                         "the driver's direct two-file ingest (no joined copy of the files)")
     ap.add_argument("--sweep", default="", help="threads:batches pairs to run after the two standard runs, e.g. 16:64,16:128,32:64")
     ap.add_argument("--load-times", action="store_true",
                     help="also time tools/load_time.py on the files: 1 member, 2 and 3 members (parts) on this card, with this "
@@ -153,6 +156,22 @@ def run(a, out, dev, work):
         r = synth_gpu.host_driver_run(exe, work, K, T, fq, a.reads, threads=t_, batches=b_, truth=truth)
         print("sweep -n %d -b %d: %.2f Mreads/s, wall %.1f s | %s" % (t_, b_, r["Mreads_per_s"], r["wall_s"], " | ".join(r["timing"])), flush=True)
         out.setdefault("sweep", []).append({"threads": t_, "batches": b_, "Mreads_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"]})
+    if a.paired:
+        # mate files: the same records with /1 and /2 behind the id (the ids match after the cut at '/', src/file.cc:205-268)
+        f1, f2 = os.path.join(work, "r_1.fq"), os.path.join(work, "r_2.fq")
+        rec = np.fromfile(fq, dtype=np.uint8).reshape(-1, synth_gpu.FASTQ_RECORD)
+        n_pairs = min(a.reads, 20_000_000)
+        for path, tag in ((f1, b"/1"), (f2, b"/2")):
+            m = rec[:n_pairs].copy()
+            m[:, 10:12] = np.frombuffer(tag, dtype=np.uint8)
+            m.tofile(path)
+            del m
+        del rec
+        r = synth_gpu.host_driver_run(exe, work, K, T, f1, n_pairs, threads=a.threads, batches=a.batches, fastq2=f2)
+        assert r["csv_lines"] == n_pairs, r
+        print("paired: %d pairs of 2 x 150 bp from two files: %.2f M pairs/s, wall %.1f s | %s" % (n_pairs, r["Mreads_per_s"], r["wall_s"], " | ".join(r["timing"])), flush=True)
+        out["e2e_host_paired"] = {"pairs": n_pairs, "Mpairs_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"], "timing": r["timing"]}
+        os.remove(f1); os.remove(f2)
     out["e2e_host"] = {"reads": a.reads, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "runs": runs,
                        "Mreads_per_s": max(x["Mreads_per_s"] for x in runs),
                        "what": "bin/cuCLARK -k 31 -O reads.fq: FASTQ text -> index -> pack -> GPU -> CSV text, the program's own timer "
