@@ -159,7 +159,7 @@ int mc_index_next_pass(mc_ctx *ctx);
 int mc_index_end(mc_ctx *ctx);
 
 /* The loader's arithmetic, without a device: how a table of n_keys_total k-mers spread over n_parts contexts with
- * hbm_bytes of free HBM each would be laid out -- k-mers per line (the sparsest of 4 .. 12 that fits, 16 GB kept in
+ * hbm_bytes of free HBM each would be laid out -- k-mers per line (the sparsest of 3 .. 12 that fits, 16 GB kept in
  * reserve), primary lines and bytes per part, whether it fits at all, and the smallest part count that holds the
  * table at no more than MC_GROUP_MAX_FILL k-mers per line (what mc_group_load_db cuts it into; 0 = more than 4096).
  * replaces: the memory budget of CuClarkDB::read (CuClarkDB.cu:516-559: minParts, m_partPointer).

@@ -114,7 +114,7 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     index_abort(c);
     // k-mers per 12-slot line.  Fewer per line = fewer overflowing lines = a faster kernel (genome-shaped table,
     // 5.5e9 k-mers: 4 / 5 / 6 / 8 per line -> 993 / 913 / 828 / 705 Mreads/s at 193 / 161 / 140 / 126 GB), so a table
-    // that is alone on the card takes the room it finds: the sparsest fill in [4, 12] that leaves 16 GB free.
+    // that is alone on the card takes the room it finds: the sparsest fill in [3, 12] that leaves 16 GB free.
     // Parts of one table must agree on the fill: a caller that builds the parts one by one (mc_load_db_part,
     // mc_index_begin with n_parts > 1) gets the fill every part can afford IF each has a card like this one to
     // itself -- a pure function of (n_keys_total, n_parts, HBM of the card) -- unless a group loader chose
@@ -829,7 +829,9 @@ double choose_fill(uint64_t n_keys_total, uint32_t n_parts, uint64_t free_bytes)
     auto fits = [&](double f) {
         return lines_per_part(n_keys_total, n_parts, f) != 0 && index_bytes(n_keys_total, n_parts, f) + MZ_RESERVE_BYTES <= free_bytes;
     };
-    for (double f = 4.0; f < 8.0; f += 0.5)
+    // (round 3: from 3 per line, not 4 -- where the card has the room, the genome-shaped table gains 4 % at 3 and the
+    // headline table 1 % at 3.5: fewer lines on which related genomes and background k-mers meet)
+    for (double f = 3.0; f < 8.0; f += 0.5)
         if (fits(f)) return f;
     // past 8 the lines are mostly full and the chains long: slower, but the table stays on the card
     for (double f = 8.0; f < 12.0; f += 1.0)

@@ -83,7 +83,7 @@ def test_index_plan_respects_the_line_space_and_the_budget(n_keys):
         __graft_entry__.build()
     for n_parts in range(1, 9):
         p = _lib.index_plan(n_keys, n_parts, CARD)
-        assert 4.0 <= p["fill"] <= 12.0
+        assert 3.0 <= p["fill"] <= 12.0
         share = n_keys / n_parts
         if p["fits"]:
             assert 0 < p["lines_per_part"] < 0xFFFFFFF0
@@ -94,8 +94,8 @@ def test_index_plan_respects_the_line_space_and_the_budget(n_keys):
         else:
             # does not fit even at 12 per line: more than ~12e9 k-mers per card
             assert share > 11e9, (n_keys, n_parts, p)
-        # the sparsest fill is taken: one step sparser would not fit (or we are at 4)
-        if p["fits"] and p["fill"] > 4.0:
+        # the sparsest fill is taken: one step sparser would not fit (or we are at 3)
+        if p["fits"] and p["fill"] > 3.0:
             q = _lib.index_plan(n_keys, n_parts, CARD - 1)      # monotone in the budget
             assert q["fill"] >= p["fill"]
     p8 = _lib.index_plan(n_keys, 8, CARD)
@@ -110,11 +110,11 @@ def test_index_plan_respects_the_line_space_and_the_budget(n_keys):
 
 
 def test_index_plan_examples_of_the_review():
-    """configs[3]/[4] scale: 32e9 k-mers.  8 cards: fill 4, 1.0e9 lines each; one card cannot hold it; the
+    """configs[3]/[4] scale: 32e9 k-mers.  8 cards: fill 3, 1.33e9 lines each; one card cannot hold it; the
     line limit itself (2^32 - 16 lines per part) is only reached beyond what any card holds."""
     from jn_cuclark_amd import _lib
     p = _lib.index_plan(32_000_000_000, 8, CARD)
-    assert p["fits"] == 1 and p["fill"] == 4.0 and p["lines_per_part"] == (32_000_000_000 // 4 + 1024 + 7) // 8
+    assert p["fits"] == 1 and p["fill"] == 3.0 and p["lines_per_part"] == (int(32_000_000_000 / 3.0) + 1024 + 7) // 8
     assert p["min_parts"] == 3                                        # 32e9 / 3 = 10.7e9 per card at 10 per line
     assert _lib.index_plan(32_000_000_000, 1, CARD)["fits"] == 0
     assert _lib.index_plan(32_000_000_000, 4096, CARD)["fits"] == 1    # part 0 of 4096: a few MB
