@@ -69,7 +69,12 @@ int mc_group_close(mc_group *g);
  * overrides AUTO; MC_GROUP_HBM_BYTES caps the per-device memory the choice assumes; MC_GROUP_PARTS=S fixes the
  * part count of a sharded table).  Capacity: a part addresses 2^32 - 16 lines of its own (csrc/mc_minimizer.hpp
  * part_of), so N cards hold what their HBM holds: about 12e9 k-mers per 288 GB card at the densest fill.
- * AUTO that finds its estimate too kind (MC_ENOMEM while loading) cuts the table into more parts and tries again. */
+ * AUTO that finds its estimate too kind (MC_ENOMEM while loading) cuts the table into more parts and tries again;
+ * when the minimizer lines fit in no cut, the bucket-line table is the last resort (whole on every member when it fits
+ * one, else the reference's bucket ranges, CuClarkDB.cu:552-559; mc_db_info.index_fallback = 1, said on stderr).
+ * A table LARGER THAN ALL DEVICES TOGETHER IS REFUSED (MC_ENOMEM, "use more devices"): the reference would cycle
+ * database parts through the devices and re-query every batch per cycle (swapDbParts, CuClarkDB.cu:775-815,
+ * src/CuCLARK_hh.hh:1765-1772) -- there is no such cycling here; 8 x 288 GB hold about 90e9 k-mers. */
 int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t sampling, int mode);
 int mc_group_get_info(mc_group *g, mc_group_info *out);
 /* the member contexts, for mc_get_db_info / mc_get_stats */

@@ -136,6 +136,13 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     c->info = mc_db_info{};
     c->info.part = part; c->info.n_parts = n_parts;
     const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
+    // MC_MZ_ALLOC_LIMIT (bytes): a cap on the lines of one context -- a card shared with other tenants, and how the tests
+    // reach the "does not fit" paths (the fallback to the bucket-line table, a group that cuts the table into more parts)
+    if (const char *e = getenv("MC_MZ_ALLOC_LIMIT")) {
+        const uint64_t lim = strtoull(e, nullptr, 10);
+        if (lim && (uint64_t)lbytes > lim)
+            return fail(MC_ENOMEM, "minimizer lines of " + std::to_string(lbytes) + " bytes exceed MC_MZ_ALLOC_LIMIT");
+    }
     // room for the extra lines behind the primary lines, in the same allocation (mc_internal.hpp): the share the
     // loader's budget assumes for this fill (index_bytes), which a genome-shaped table stays below
     uint64_t reserve = (uint64_t)((double)c->mz_n_local * mcint::extra_share(per_line)) + 64;
@@ -189,12 +196,12 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
     HIPCHK(hipGetLastError());
     if (c->build.pass == 0)
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
-                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, B.d_koff, c->k, c->mz_m,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, n_keys, b0, c->htsize, B.d_koff, c->k, c->mz_m,
                            c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
                            (uint8_t *)nullptr, (uint8_t *)nullptr, B.d_failed);
     else
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
-                           static_cast<const key_t *>(d_keys), d_labels, nb, b0, c->htsize, B.d_koff, c->k, c->mz_m,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, n_keys, b0, c->htsize, B.d_koff, c->k, c->mz_m,
                            c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
                            c->d_mz_lines, c->d_mz_extra, B.d_failed);
     HIPCHK(hipGetLastError());
@@ -921,9 +928,11 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
             HIPCHK(hipSetDevice(D.device));
             HIPCHK(hipStreamCreateWithFlags(&D.cs, hipStreamNonBlocking));
             for (int s2 = 0; s2 < 2; s2++) {
-                HIPCHK(hipMalloc(&D.d_sz[s2], cap_b));
-                HIPCHK(hipMalloc(&D.d_keys[s2], cap_k * kb));
-                HIPCHK(hipMalloc(&D.d_labels[s2], cap_k * 2));
+                if (hipMalloc(&D.d_sz[s2], cap_b) != hipSuccess || hipMalloc(&D.d_keys[s2], cap_k * kb) != hipSuccess ||
+                    hipMalloc(&D.d_labels[s2], cap_k * 2) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(MC_ENOMEM, "not enough HBM for the loader's staging chunks next to the minimizer lines");
+                }
                 HIPCHK(hipEventCreateWithFlags(&D.copied[s2], hipEventDisableTiming));
             }
         }
@@ -1008,6 +1017,38 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
     return rc;
 }
 
+
+// The bucket-line table from the files: the raw arrays of the range go to the device whole.  The fallback of every
+// loader when the minimizer lines do not fit (`fallback` says so in mc_db_info).
+int load_lines_from_files(mc_ctx *c, DbFileStream &F, uint64_t sb, uint64_t se, bool fallback)
+{
+    const int key_bytes = F.key_bytes;
+    int rc = MC_OK;
+    const uint64_t nb = se - sb, kept = F.n_keys_kept;
+    Scope tmp;
+    uint8_t *d_sz = nullptr; char *d_raw = nullptr; uint16_t *d_labels = nullptr;
+    TMP_MALLOC(tmp, d_sz, nb ? nb : 1);
+    TMP_MALLOC(tmp, d_raw, (kept ? kept : 1) * (size_t)key_bytes);
+    TMP_MALLOC(tmp, d_labels, (kept ? kept : 1) * 2);
+    uint64_t dpos = 0;
+    rc = F.pass([&](const uint8_t *, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t, uint64_t) {
+        if (nk) {
+            HIPCHK(hipMemcpy(d_raw + dpos * (size_t)key_bytes, keys, nk * (size_t)key_bytes, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_labels + dpos, labels, nk * 2, hipMemcpyHostToDevice));
+        }
+        dpos += nk;
+        return (int)MC_OK;
+    });
+    if (rc) return rc;
+    if (dpos != kept) return fail(MC_EINVAL, "internal: kept-key count mismatch");
+    HIPCHK(hipMemcpy(d_sz, F.sz.data() + sb, nb, hipMemcpyHostToDevice));
+    void *d_keys = nullptr; bool owned = false;
+    tmp.forget(d_raw);                       // convert_keys takes it over (frees or returns it)
+    rc = convert_keys(c, d_raw, key_bytes, kept, true, &d_keys, &owned);
+    if (rc != MC_OK) return rc;
+    tmp.add(d_keys);
+    return relayout(c, d_sz, d_keys, d_labels, kept, sb, se, fallback);
+}
 } // namespace mcint
 
 using mcint::launch_query;
@@ -1154,31 +1195,7 @@ int mc_load_db(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, ui
         fprintf(stderr, "libmcclark: %s; falling back to the bucket-line table\n", g_err.c_str());
         fallback = true;
     }
-    // bucket-line table: the raw arrays of the shard go to the device whole
-    const uint64_t nb = se - sb, kept = F.n_keys_kept;
-    Scope tmp;
-    uint8_t *d_sz = nullptr; char *d_raw = nullptr; uint16_t *d_labels = nullptr;
-    TMP_MALLOC(tmp, d_sz, nb ? nb : 1);
-    TMP_MALLOC(tmp, d_raw, (kept ? kept : 1) * (size_t)key_bytes);
-    TMP_MALLOC(tmp, d_labels, (kept ? kept : 1) * 2);
-    uint64_t dpos = 0;
-    rc = F.pass([&](const uint8_t *, const void *keys, const uint16_t *labels, uint64_t nk, uint64_t, uint64_t) {
-        if (nk) {
-            HIPCHK(hipMemcpy(d_raw + dpos * (size_t)key_bytes, keys, nk * (size_t)key_bytes, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_labels + dpos, labels, nk * 2, hipMemcpyHostToDevice));
-        }
-        dpos += nk;
-        return (int)MC_OK;
-    });
-    if (rc) return rc;
-    if (dpos != kept) return fail(MC_EINVAL, "internal: kept-key count mismatch");
-    HIPCHK(hipMemcpy(d_sz, F.sz.data() + sb, nb, hipMemcpyHostToDevice));
-    void *d_keys = nullptr; bool owned = false;
-    tmp.forget(d_raw);                       // convert_keys takes it over (frees or returns it)
-    rc = convert_keys(c, d_raw, key_bytes, kept, true, &d_keys, &owned);
-    if (rc != MC_OK) return rc;
-    tmp.add(d_keys);
-    return relayout(c, d_sz, d_keys, d_labels, kept, sb, se, fallback);
+    return mcint::load_lines_from_files(c, F, sb, se, fallback);
 }
 
 int mc_load_db_part(mc_ctx *c, const char *base, int key_bytes, uint32_t sampling, uint32_t part, uint32_t n_parts)

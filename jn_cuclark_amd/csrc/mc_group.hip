@@ -273,6 +273,33 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
         g->S = mode == MC_GROUP_SHARDS ? S : 1; g->G = mode == MC_GROUP_SHARDS ? G : n;
         break;
     }
+    if (rc == MC_ENOMEM && mz) {
+        // Last resort, whatever the mode asked for: the bucket-line table (about 3x slower to query, a third of the
+        // memory at dense fills) -- whole on every member when it fits one, else cut by the reference's bucket ranges
+        // (CuClarkDB.cu:552-559).  Said aloud; mc_db_info of the members carries index_fallback = 1.
+        fprintf(stderr, "libmcclark: %s; falling back to the bucket-line table\n", mc_last_error());
+        std::vector<int> saved(n);
+        for (uint32_t m = 0; m < n; m++) { saved[m] = g->ctx[m]->index_mode; g->ctx[m]->index_mode = 0; }
+        bool whole = mode == MC_GROUP_REPLICAS || n == 1;
+        if (whole) {
+            for (uint32_t m = 0; m < n; m++) {
+                rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, 0, 0);
+                if (rc != MC_OK) break;
+            }
+            if (rc == MC_OK) { mode = MC_GROUP_REPLICAS; shard_kind = 0; g->S = 1; g->G = n; }
+        }
+        if (n > 1 && (!whole || rc == MC_ENOMEM)) {
+            for (uint32_t m = 0; m < n; m++) {
+                rc = mc_load_db(g->ctx[m], base, key_bytes, sampling, g->htsize * m / n, g->htsize * (m + 1) / n);
+                if (rc != MC_OK) break;
+            }
+            if (rc == MC_OK) { mode = MC_GROUP_SHARDS; shard_kind = 2; g->S = n; g->G = 1; }
+        }
+        for (uint32_t m = 0; m < n; m++) {
+            g->ctx[m]->index_mode = saved[m];
+            if (rc == MC_OK) g->ctx[m]->info.index_fallback = 1u;
+        }
+    }
     if (rc == MC_ENOMEM)
         return fail(MC_ENOMEM, std::string("the database does not fit the ") + std::to_string(n) + " device(s) of the group (" +
                                    mc_last_error() + "); use more devices (-d)");

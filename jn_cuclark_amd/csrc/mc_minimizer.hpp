@@ -47,7 +47,8 @@ static constexpr int MZ_CAP1 = MZ_CAP - 1;
 static constexpr uint32_t MZ_CHAIN_CAP = (uint32_t)MZ_CAP1 + (uint32_t)MZ_CAP * MZ_EMAX;   // k-mers a line keeps (first + extra lines)
 // dword 30 of a primary line: bits 0-1 = lines per chain (0..MZ_EMAX), bit 2 = a lookup also scans the chain behind
 // its own (some chain was full when the table was built), bits 3-7 = s: the line has 2^s chains and a k-mer's chain
-// is picked by a hash of the k-mer (0: one chain), bit 16 = the line has extra lines (the header of any other line is 0)
+// is picked by a hash of the k-mer (0: one chain), bit 16 = the line has extra lines (the header of a primary line that
+// does not overflow is 0; EXTRA lines carry no header -- they are memset to 0xFF and their dwords 30-31 are never read)
 static constexpr uint32_t MZ_HDR_LEN = 3u;
 static constexpr uint32_t MZ_HDR_CHAIN = 0x10000u;
 static constexpr uint32_t MZ_HDR_TWO = 4u;
@@ -266,7 +267,7 @@ __host__ __device__ __forceinline__ uint32_t seg_log_of(uint32_t c)
 template <int PASS, bool WIDE>
 __global__ __launch_bounds__(RL_THREADS)
 void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, const uint16_t *labels,
-                     uint64_t n_buckets, uint64_t bucket0, uint64_t htsize, const uint64_t *blk_key_off,
+                     uint64_t n_buckets, uint64_t n_keys, uint64_t bucket0, uint64_t htsize, const uint64_t *blk_key_off,
                      uint32_t k, uint32_t m, uint32_t part, uint32_t n_parts, uint32_t n_local,
                      uint32_t *count, uint8_t *lines, uint8_t *extra_lines, unsigned int *failed)
 {
@@ -281,6 +282,9 @@ void mz_build_kernel(const uint8_t *sz, const typename KeyOf<WIDE>::type *keys, 
         const uint64_t b = b0 + i;
         if (b >= n_buckets) break;
         for (uint32_t j = 0; j < cnt[i]; j++) {
+            // a chunk whose bucket sizes announce more k-mers than the caller passed (mz_scan_blocks_kernel flags it, the
+            // build ends with MC_EINVAL at the next pass boundary): nothing is read past the arrays meanwhile
+            if (koff + j >= n_keys) break;
             const uint64_t c = (uint64_t)keys[koff + j] * htsize + (bucket0 + b);     // the canonical k-mer
             const uint64_t K = kmer_min_key(c, k, m);
             if (n_parts > 1u && part_of(K, n_parts) != part) continue;               // another part's k-mer
@@ -1174,7 +1178,6 @@ void mz_query_kernel(const MzArgs A)
                                     __builtin_amdgcn_wave_barrier();
                                 }
                                 // still pending: not found yet and another line in the chain
-#pragma unroll
                                 MZ_STAT(12, __popcll(found[0]) + __popcll(found[1]));            // found in a chain
 #pragma unroll
                                 for (int s = 0; s < MZ_NS; s++) {

@@ -93,6 +93,26 @@ class ShardedClassifier:
         self.n_chunks = n_chunks
         self._bufs = {}          # (slot, per) -> (send, recv)
         self._gloo = dist.get_backend(group) == "gloo"
+        self._check_layout()
+
+    def _check_layout(self):
+        """The parts of one table must have been built with ONE layout: line_of(K, lines per part) is part of the
+        address of every k-mer, so a rank whose part came out at another fill (another MC_MZ_FILL, a card of another
+        size, a card that held something else) would answer for lines nobody asks it about -- silently.  Compared
+        across the group before the first batch; a mismatch is an error, not a slower run."""
+        lay = getattr(self.be, "layout", None)
+        if lay is None or self.world == 1:
+            return
+        mine = lay()
+        all_ = [None] * self.world
+        dist.all_gather_object(all_, mine, group=self.group)
+        # (bucket-range shards -- n_parts 1 -- are indexes of their own, each with its own line count)
+        by_lines = all_[0][1] > 1
+        same = all(a[:2] == all_[0][:2] and (not by_lines or a[2] == all_[0][2]) for a in all_)
+        parts = sorted(a[3] for a in all_)
+        if not same or (by_lines and parts != list(range(self.world))):
+            raise RuntimeError("the parts of the sharded table disagree on their layout (index kind, parts, lines per part, part): %r "
+                               "-- build every part with the same fill (MC_MZ_FILL) on cards of one size" % (all_,))
 
     def _buffers(self, slot, per):
         key = (slot, per)
@@ -243,6 +263,11 @@ class HipBackend:
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def layout(self):
+        """(index kind, parts, lines per part, this part) of the part held here: ShardedClassifier compares them across the group"""
+        i = self.db.db_info()
+        return (int(i["index_kind"]), int(i["n_parts"]), int(i["line_end"] - i["line_begin"]), int(i["part"]))
 
     def query_rows_into(self, reads_ptr, containers, r0, r1, out):
         # the offsets of reads [r0, r1] stay absolute: the kernel indexes the whole container array with them

@@ -362,7 +362,7 @@ def pick_dir(need_bytes, want=None):
     return None
 
 
-def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches=32, truth=None, check=200_000, fastq2=None):
+def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches=32, truth=None, check=200_000, fastq2=None, timeout=600):
     """`exe -k K -T targets -D work -O fastq -R work/res` (the database files must be in `work` under the reference's
     name, src/CuCLARK_hh.hh:586-590): returns the program's own rate ("Done in Xs (N reads/min, M reads)", the
     reference's timer, src/CuCLARK_hh.hh:552-563, :1931-1939: file -> CSV, the database load is outside it), the wall
@@ -380,7 +380,7 @@ def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches
     t0 = _t.time()
     inputs = ["-P", fastq, fastq2] if fastq2 else ["-O", fastq]          # -P: paired-end mates in two files (src/main.cc:43-69)
     r = subprocess.run([exe, "-k", str(k), "-T", os.path.join(work, "targets.txt"), "-D", work] + inputs + ["-R", os.path.join(work, "res"),
-                        "-n", str(threads), "-b", str(batches), "--verbose"], capture_output=True, text=True)
+                        "-n", str(threads), "-b", str(batches), "--verbose"], capture_output=True, text=True, timeout=timeout)      # TimeoutExpired: the caller's to report
     wall = _t.time() - t0
     if r.returncode != 0:
         raise RuntimeError("host driver failed: " + r.stderr[-500:])

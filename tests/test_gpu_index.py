@@ -263,3 +263,25 @@ def test_a_second_pass_with_other_kmers_is_refused_not_written_out_of_bounds(gpu
         # the context is usable afterwards
         db.read_arrays(*ta)
         assert db.db_info()["n_keys"] == n
+
+
+def test_a_chunk_with_fewer_kmers_than_its_bucket_sizes_say_is_refused(gpu, oracle):
+    """mc_index_add_* with n_keys below the sum of the chunk's bucket sizes: the build kernels must not read past the
+    arrays the caller passed (they stop at n_keys), the mismatch is reported as MC_EINVAL at the pass boundary, and the
+    context loads the next table as if nothing had happened."""
+    import ctypes as C
+    from jn_cuclark_amd import McError
+    from jn_cuclark_amd._lib import check
+    _, sz, ky, lb = small_db(n_targets=4, glen=5000)
+    n = int(ky.size)
+    short = n - 1000
+    with gpu(k=K, numBatches=1, numTargets=4, device=0, htsize=HT, maxhits=15) as db:
+        check(db._lib.mc_index_begin(db._h, short, 0, 1))
+        # the arrays really are `short` long: anything read behind them is out of bounds
+        ky_s, lb_s = np.ascontiguousarray(ky[:short]), np.ascontiguousarray(lb[:short])
+        check(db._lib.mc_index_add_host(db._h, sz.ctypes.data, ky_s.ctypes.data, ky_s.dtype.itemsize, lb_s.ctypes.data, short, 0, HT))
+        with pytest.raises(McError) as e:
+            check(db._lib.mc_index_next_pass(db._h))
+        assert "do not sum" in str(e.value)
+        db.read_arrays(sz, ky, lb)
+        assert db.db_info()["n_keys"] == n

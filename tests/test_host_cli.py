@@ -699,6 +699,10 @@ def test_fast_g_format_matches_printf(tmp_path):
     # as few parts as the budget dictates, replicated: 4 members, a table that needs 2 -> 2 parts x 2 groups
     ("0,0,0,0", {"MC_GROUP_HBM_BYTES": "fit2"}, "shards by minimizer line range: 2 parts x 2 groups"),
     ("0,0,0,0,0", {"MC_GROUP_MODE": "shards", "MC_GROUP_PARTS": "2"}, "shards by minimizer line range: 2 parts x 2 groups"),
+    # the minimizer lines "do not fit" anywhere (MC_MZ_ALLOC_LIMIT): one member falls back to the bucket-line table, two
+    # members first cut the table into parts, then fall back to the reference's bucket ranges
+    ("0", {"MC_MZ_ALLOC_LIMIT": "65536"}, "replicas"),
+    ("0,0", {"MC_MZ_ALLOC_LIMIT": "65536"}, "shards by bucket range"),
 ])
 @pytest.mark.parametrize("extended", [False, True])
 def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members, env, expect, extended):
@@ -747,6 +751,8 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
                           capture_output=True, text=True, timeout=900, env=e)
     assert many.returncode == 0, many.stderr
     assert ("Devices: %d (%s" % (len(members.split(",")), expect)) in many.stderr, many.stderr
+    if "MC_MZ_ALLOC_LIMIT" in env:
+        assert "falling back to the bucket-line table" in many.stderr and "[fallback: the minimizer index did not fit]" in many.stderr, many.stderr
     if "replicas" not in expect and "parts x" not in expect:
         assert ("%d parts x 1 groups" % len(members.split(","))) in many.stderr, many.stderr
     a, b = open(str(tmp_path / "one.csv")).read(), open(str(tmp_path / "many.csv")).read()
