@@ -203,13 +203,13 @@ def main():
         os.environ.pop("MC_MZ_FILL", None)
     info = db.db_info()
     torch.cuda.synchronize()
-    index = "minimizer" if info["index_kind"] == 1 else "lines"
+    index = {1: "minimizer", 2: "skm"}.get(info["index_kind"], "lines")
     if rank == 0:
         log("db: %.2fe9 k-mers, %s index, %.1f GB in HBM, %.2f %% of the %s overflow, largest line %d k-mers, built in %.1fs"
             % (n_keys / 1e9, index, info["device_bytes"] / 1e9,
-               100.0 * (info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]) if index == "minimizer"
+               100.0 * (info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]) if index != "lines"
                         else info["n_overflow_buckets"] / ht),
-               "lines" if index == "minimizer" else "buckets", info["largest_line"], time.time() - t0))
+               "lines" if index != "lines" else "buckets", info["largest_line"], time.time() - t0))
 
     # ---- reads in HBM ------------------------------------------------------------
     n_reads = args.reads
@@ -290,6 +290,7 @@ def main():
         achieved = bytes_per_read * n_reads / (kern_ms_avg * 1e-3) / 1e9
         # (the k-mer length is compiled in for k = 31 and 27, csrc/mc_minimizer.hpp)
         kernel_name = ("mc::mz::mz_query_kernel<%d, %d>" % (2 if shard_mode else 0, k if k in (31, 27) else 0)) if index == "minimizer" \
+            else ("mc::sk::sk_query_kernel<%d, %d>" % (2 if shard_mode else 0, k if k in (31, 27) else 0)) if index == "skm" \
             else "mc::query_kernel<%d, false>" % info["line_bytes"]
         # HBM traffic per launch comes from a rocprofv3 --pmc run of this same command (tools/prof_pmc.sh writes
         # profiles/traffic.json): counters cannot be read from inside the process.  The figure is used only if it

@@ -69,7 +69,7 @@ typedef struct mc_db_info {
     uint32_t line_capacity;   /* k-mers per line                                     */
     uint64_t device_bytes;    /* HBM held by the database                            */
     /* --- version 2 --- */
-    uint32_t index_kind;      /* MC_INDEX_BUCKET_LINES or MC_INDEX_MINIMIZER: which in-HBM index was built */
+    uint32_t index_kind;      /* MC_INDEX_BUCKET_LINES, MC_INDEX_MINIMIZER or MC_INDEX_SUPERKMER: which in-HBM index was built */
     uint32_t index_fallback;  /* 1: the minimizer index was wanted but did not fit; bucket lines were built
                                  (also reported on stderr)                                                 */
     uint32_t part, n_parts;   /* line-range part of a table spread over n_parts contexts (0 of 1 = whole)  */
@@ -88,6 +88,7 @@ typedef struct mc_db_info {
 
 #define MC_INDEX_BUCKET_LINES 0u
 #define MC_INDEX_MINIMIZER    1u
+#define MC_INDEX_SUPERKMER    2u   /* records of up to 9 k-mers stored relative to their minimizer (csrc/mc_skm.hpp): MC_INDEX=skm */
 
 typedef struct mc_stats {
     uint64_t reads;               /* reads classified since mc_open                  */

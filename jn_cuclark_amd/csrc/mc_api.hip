@@ -6,6 +6,7 @@
 // that needs one fails with MC_ENODEVICE / MC_EHIP.
 #include "mc_internal.hpp"
 #include "mc_minimizer.hpp"
+#include "mc_skm.hpp"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -58,6 +59,9 @@ void free_db(mc_ctx *c)
     if (c->d_ovf_labels) (void)hipFree(c->d_ovf_labels);
     if (c->d_mz_lines) (void)hipFree(c->d_mz_lines);
     if (c->d_mz_extra && c->mz_extra_own_alloc) (void)hipFree(c->d_mz_extra);
+    if (c->d_sk_lines) (void)hipFree(c->d_sk_lines);
+    if (c->d_sk_extra) (void)hipFree(c->d_sk_extra);
+    c->d_sk_lines = nullptr; c->d_sk_extra = nullptr; c->sk_n_lines = 0;
     c->mz_extra_own_alloc = false; c->mz_extra_reserved = 0;
     c->d_lines = nullptr; c->d_ovf_keys = nullptr; c->d_ovf_labels = nullptr;
     c->d_mz_lines = nullptr; c->d_mz_extra = nullptr;
@@ -95,6 +99,10 @@ void index_abort(mc_ctx *c)
     if (c->build.d_st_sz) (void)hipFree(c->build.d_st_sz);
     if (c->build.d_st_keys) (void)hipFree(c->build.d_st_keys);
     if (c->build.d_st_labels) (void)hipFree(c->build.d_st_labels);
+    if (c->build.d_cursor) (void)hipFree(c->build.d_cursor);
+    if (c->build.d_off32) (void)hipFree(c->build.d_off32);
+    if (c->build.d_blk_base) (void)hipFree(c->build.d_blk_base);
+    if (c->build.d_entries) (void)hipFree(c->build.d_entries);
     c->build = mcint::IndexBuild();
 }
 
@@ -105,9 +113,15 @@ bool mz_eligible(const mc_ctx *c, uint64_t n_keys_total)
     return c->k >= 16 && mz_m >= 6 && (mz_m >= 20 || (1ull << (2 * mz_m - 1)) >= 4 * (n_keys_total / 6 + 1024));
 }
 
+int sk_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts);
+int sk_next_pass(mc_ctx *c);
+int sk_end(mc_ctx *c);
+bool use_sk(const mc_ctx *c) { return c->index_mode == 2 && mc::sk::sk_supported(c->k); }
+
 int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts)
 {
     if (n_parts < 1 || part >= n_parts) return fail(MC_EINVAL, "bad part / n_parts");
+    if (use_sk(c)) return sk_begin(c, n_keys_total, part, n_parts);
     if (!mz_eligible(c, n_keys_total))
         return fail(MC_EINVAL, "the minimizer index needs k >= 16 and a minimizer space above the line count");
     free_db(c);
@@ -194,7 +208,18 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mc::mz::mz_scan_blocks_kernel, dim3(1), dim3(256), 0, st, B.d_blk, nblk, B.d_koff, n_keys, B.d_failed);
     HIPCHK(hipGetLastError());
-    if (c->build.pass == 0)
+    if (B.sk) {
+        if (c->build.pass == 0)
+            hipLaunchKernelGGL((mc::sk::sk_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                               static_cast<const key_t *>(d_keys), d_labels, nb, n_keys, b0, c->htsize, B.d_koff, c->k, c->mz_m,
+                               c->mz_part, c->mz_n_parts, B.sk_n_fine, B.d_count, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                               (const uint64_t *)nullptr, (mc::sk::SkSlot *)nullptr, B.d_failed);
+        else
+            hipLaunchKernelGGL((mc::sk::sk_build_kernel<1, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                               static_cast<const key_t *>(d_keys), d_labels, nb, n_keys, b0, c->htsize, B.d_koff, c->k, c->mz_m,
+                               c->mz_part, c->mz_n_parts, B.sk_n_fine, B.d_cursor, B.d_count, B.d_off32, B.d_blk_base,
+                               static_cast<mc::sk::SkSlot *>(B.d_entries), B.d_failed);
+    } else if (c->build.pass == 0)
         hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
                            static_cast<const key_t *>(d_keys), d_labels, nb, n_keys, b0, c->htsize, B.d_koff, c->k, c->mz_m,
                            c->mz_part, c->mz_n_parts, c->mz_n_local, c->build.d_count,
@@ -278,6 +303,7 @@ int index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes
 int index_next_pass(mc_ctx *c)
 {
     if (!c->build.open || c->build.pass != 0) return fail(MC_ESTATE, "mc_index_next_pass out of order");
+    if (c->build.sk) return sk_next_pass(c);
     hipStream_t st = c->streams[0];
     const uint64_t n = c->mz_n_local;
     const uint32_t nblk = (uint32_t)std::max<uint64_t>(1, (n + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
@@ -327,6 +353,7 @@ int index_next_pass(mc_ctx *c)
 int index_end(mc_ctx *c)
 {
     if (!c->build.open || c->build.pass != 1) return fail(MC_ESTATE, "mc_index_end out of order");
+    if (c->build.sk) return sk_end(c);
     if (c->build.fed[0] != c->build.fed[1]) { free_db(c); index_abort(c); return fail(MC_EINVAL, "the two passes were fed different k-mer counts"); }
     hipStream_t st = c->streams[0];
     if (c->build.n_over && !getenv("MC_MZ_NO_REGROUP")) {      // whole minimizer groups first in overflowing lines
@@ -392,6 +419,204 @@ int index_end(mc_ctx *c)
     return MC_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// super-k-mer index (mc_skm.hpp): the same two passes over the chunks; the final line count is chosen at the end
+// ---------------------------------------------------------------------------
+static const uint32_t SK_D_LCM = 27720;          // every merge factor d in 1 .. 12 divides the fine line count
+
+int sk_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts)
+{
+    free_db(c);
+    index_abort(c);
+    // fine lines: about one per two k-mers of this part (the final lines are 1 .. 12 of them each)
+    double per_fine = 2.0;
+    if (const char *e = getenv("MC_SKM_FINE")) { const double v = atof(e); if (v >= 0.25 && v <= 64.0) per_fine = v; }
+    uint64_t want = (uint64_t)((double)n_keys_total / (double)n_parts / per_fine) + 1;
+    want = (want + SK_D_LCM - 1) / SK_D_LCM * SK_D_LCM;
+    if (want >= mcint::MZ_MAX_LINES) want = mcint::MZ_MAX_LINES / SK_D_LCM * SK_D_LCM;
+    mcint::IndexBuild &B = c->build;
+    B.sk = true; B.sk_n_fine = (uint32_t)want;
+    c->mz_part = part; c->mz_n_parts = n_parts; c->mz_m = mc::mz::mmer_len(c->k);
+    c->info = mc_db_info{};
+    c->info.part = part; c->info.n_parts = n_parts;
+    const size_t nb = (size_t)want * 4;
+    if (hipMalloc(&B.d_count, nb) != hipSuccess || hipMalloc(&B.d_cursor, nb) != hipSuccess || hipMalloc(&B.d_off32, nb) != hipSuccess ||
+        hipMalloc(&B.d_blk_base, ((size_t)(want / mc::RL_BUCKETS) + 2) * 8) != hipSuccess || hipMalloc(&B.d_failed, 4) != hipSuccess) {
+        (void)hipGetLastError();
+        index_abort(c);
+        return fail(MC_ENOMEM, "not enough HBM for the counters of " + std::to_string(want) + " fine lines");
+    }
+    hipStream_t st = c->streams[0];
+    HIPCHK(hipMemsetAsync(B.d_count, 0, nb, st));
+    HIPCHK(hipMemsetAsync(B.d_failed, 0, 4, st));
+    B.open = true; B.pass = 0; B.n_keys_total = n_keys_total;
+    return MC_OK;
+}
+
+// exclusive scan of n u32 counters: off32 (offset inside the counter's workgroup of 1024) + blk_base (u64 per workgroup, the
+// total behind the last); d_blk_tot is scratch of (n / 1024 + 1) u32
+static int sk_scan(mc_ctx *c, const uint32_t *d_cnt, uint64_t n, uint32_t *d_off32, uint64_t *d_blk_base, uint64_t *total)
+{
+    hipStream_t st = c->streams[0];
+    const uint32_t nblk = (uint32_t)std::max<uint64_t>(1, (n + mc::RL_BUCKETS - 1) / mc::RL_BUCKETS);
+    Scope tmp;
+    uint32_t *d_tot = nullptr;
+    TMP_MALLOC(tmp, d_tot, (size_t)nblk * 4);
+    hipLaunchKernelGGL(mc::sk::sk_scan_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_cnt, n, d_off32, d_tot);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(mc::sk::sk_scan_blocks_kernel, dim3(1), dim3(256), 0, st, d_tot, nblk, d_blk_base);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(total, d_blk_base + nblk, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MC_OK;
+}
+
+int sk_next_pass(mc_ctx *c)
+{
+    mcint::IndexBuild &B = c->build;
+    hipStream_t st = c->streams[0];
+    unsigned int failed0 = 0;
+    HIPCHK(hipMemcpyAsync(&failed0, B.d_failed, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (failed0 & 4u) { free_db(c); index_abort(c); return fail(MC_EINVAL, "bucket sizes do not sum to n_keys"); }
+    uint64_t total = 0;
+    int rc = sk_scan(c, B.d_count, B.sk_n_fine, B.d_off32, B.d_blk_base, &total);
+    if (rc) return rc;
+    B.sk_n_entries = total;
+    if (hipMalloc(&B.d_entries, (size_t)(total ? total : 1) * sizeof(mc::sk::SkSlot)) != hipSuccess) {
+        (void)hipGetLastError();
+        free_db(c); index_abort(c);
+        return fail(MC_ENOMEM, "super-k-mer index: not enough HBM for " + std::to_string(total) + " entries of 16 bytes while it is built");
+    }
+    HIPCHK(hipMemsetAsync(B.d_cursor, 0, (size_t)B.sk_n_fine * 4, st));
+    HIPCHK(hipStreamSynchronize(st));
+    B.pass = 1;
+    return MC_OK;
+}
+
+int sk_end(mc_ctx *c)
+{
+    using namespace mc::sk;
+    mcint::IndexBuild &B = c->build;
+    hipStream_t st = c->streams[0];
+    if (B.fed[0] != B.fed[1]) { free_db(c); index_abort(c); return fail(MC_EINVAL, "the two passes were fed different k-mer counts"); }
+    const uint32_t n_fine = B.sk_n_fine;
+    const SkSlot *ent = static_cast<const SkSlot *>(B.d_entries);
+    uint32_t *d_nrec = B.d_cursor;                   // the cursors have done their work
+    {
+        const int gr = (int)std::min<uint64_t>(((uint64_t)n_fine + 255) / 256, (uint64_t)c->n_cu * 16);
+        hipLaunchKernelGGL(sk_records_kernel, dim3(gr), dim3(256), 0, st, B.d_count, B.d_off32, B.d_blk_base, ent, n_fine, d_nrec);
+        HIPCHK(hipGetLastError());
+    }
+    // the merge factor: the largest d whose lines overflow rarely enough and fit the card
+    Scope tmp;
+    unsigned long long *d_out = nullptr;
+    TMP_MALLOC(tmp, d_out, 12 * 6 * 8);
+    HIPCHK(hipMemsetAsync(d_out, 0, 12 * 6 * 8, st));
+    for (uint32_t d = 1; d <= 12; d++) {
+        const uint64_t nl = n_fine / d;
+        const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>((nl + 255) / 256, (uint64_t)c->n_cu * 16));
+        hipLaunchKernelGGL(sk_eval_kernel, dim3(g), dim3(256), 0, st, B.d_count, d_nrec, nl, d, d_out + (d - 1) * 6);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned long long ev[12][6];
+    unsigned int failed = 0;
+    HIPCHK(hipMemcpyAsync(ev, d_out, sizeof ev, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&failed, B.d_failed, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (failed) {
+        free_db(c); index_abort(c);
+        return fail(MC_EINVAL, (failed & 4u) ? "bucket sizes do not sum to n_keys"
+                                             : "super-k-mer index: the second pass held k-mers the first did not");
+    }
+    double max_over = 0.01;
+    if (const char *e = getenv("MC_SKM_OVERFLOW")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) max_over = v; }
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    uint32_t d = 0;
+    for (uint32_t t = 12; t >= 1; t--) {
+        const uint64_t nl = n_fine / t;
+        const uint64_t bytes = (nl + ev[t - 1][1]) * (uint64_t)SK_LINE + nl * 8 + (1ull << 30);
+        if ((double)ev[t - 1][0] <= max_over * (double)nl && bytes + (2ull << 30) <= (uint64_t)fr) { d = t; break; }
+    }
+    if (d == 0) {         // no d meets the overflow bound in the room there is: the sparsest that fits
+        for (uint32_t t = 1; t <= 12 && d == 0; t++) {
+            const uint64_t nl = n_fine / t;
+            if ((nl + ev[t - 1][1]) * (uint64_t)SK_LINE + nl * 8 + (3ull << 30) <= (uint64_t)fr) d = t;
+        }
+    }
+    if (c->fill_hint >= 1.0) d = (uint32_t)c->fill_hint;           // a group loader: one layout for all members
+    if (const char *e = getenv("MC_SKM_D")) { const int v = atoi(e); if (v >= 1 && v <= 12) d = (uint32_t)v; }
+    if (d == 0 || d > 12) { free_db(c); index_abort(c); return fail(MC_ENOMEM, "super-k-mer index: the lines do not fit the free HBM at any merge factor"); }
+    const uint32_t n_lines = n_fine / d;
+    const unsigned long long *E = ev[d - 1];
+    if (E[1] >= 0xFFFFFFF0ull) { free_db(c); index_abort(c); return fail(MC_EINVAL, "super-k-mer index: more than 2^32 extra lines"); }
+    const size_t lbytes = (size_t)n_lines * SK_LINE, xbytes = (size_t)(E[1] ? E[1] : 1) * SK_LINE;
+    uint32_t *d_xcnt = nullptr, *d_xoff = nullptr; uint64_t *d_xblk = nullptr;
+    if (hipMalloc(&c->d_sk_lines, lbytes) != hipSuccess || hipMalloc(&c->d_sk_extra, xbytes) != hipSuccess) {
+        (void)hipGetLastError();
+        free_db(c); index_abort(c);
+        return fail(MC_ENOMEM, "super-k-mer index: not enough HBM for " + std::to_string(lbytes + xbytes) + " bytes of lines");
+    }
+    TMP_MALLOC(tmp, d_xcnt, (size_t)n_lines * 4);
+    TMP_MALLOC(tmp, d_xoff, (size_t)n_lines * 4);
+    TMP_MALLOC(tmp, d_xblk, ((size_t)(n_lines / mc::RL_BUCKETS) + 2) * 8);
+    HIPCHK(hipMemsetAsync(c->d_sk_lines, 0, lbytes, st));
+    HIPCHK(hipMemsetAsync(c->d_sk_extra, 0, xbytes, st));
+    {
+        const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, (uint64_t)c->n_cu * 16));
+        hipLaunchKernelGGL(sk_extras_kernel, dim3(g), dim3(256), 0, st, B.d_count, d_nrec, (uint64_t)n_lines, d, d_xcnt);
+        HIPCHK(hipGetLastError());
+    }
+    uint64_t x_total = 0;
+    int rc = sk_scan(c, d_xcnt, n_lines, d_xoff, d_xblk, &x_total);
+    if (rc) { free_db(c); index_abort(c); return rc; }
+    if (x_total != E[1]) { free_db(c); index_abort(c); return fail(MC_EINVAL, "internal: extra lines counted twice differ"); }
+    {
+        const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_lines + 255) / 256, (uint64_t)c->n_cu * 16));
+        hipLaunchKernelGGL(sk_encode_kernel, dim3(g), dim3(256), 0, st, B.d_count, B.d_off32, B.d_blk_base, ent, d_nrec, n_lines, d,
+                           d_xoff, d_xblk, c->d_sk_lines, c->d_sk_extra, B.d_failed);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(&failed, B.d_failed, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (failed) {
+        free_db(c); index_abort(c);
+        return fail(MC_EINVAL, (failed & 1u) ? "super-k-mer index: a hashed chain overflowed" : "internal: the records of a line came out differently the second time");
+    }
+    c->sk_n_lines = n_lines;
+    mc_db_info &I = c->info;
+    I.htsize = c->htsize;
+    I.shard_begin = B.bucket_lo == ~0ull ? 0 : B.bucket_lo;
+    I.shard_end = B.bucket_hi ? B.bucket_hi : c->htsize;
+    I.n_keys = B.fed[0];
+    I.n_keys_owned = B.sk_n_entries;                    // entries: k-mers of this part, ties stored once per window
+    I.n_overflow_buckets = E[1]; I.n_overflow_keys = 0;
+    I.line_bytes = SK_LINE; I.line_capacity = SK_SLOTS * SK_W;
+    I.device_bytes = (uint64_t)lbytes + xbytes;
+    I.index_kind = MC_INDEX_SUPERKMER;
+    I.n_lines = (uint64_t)n_lines * c->mz_n_parts;
+    I.line_begin = (uint64_t)n_lines * c->mz_part; I.line_end = I.line_begin + n_lines;
+    I.n_extra_lines = E[1]; I.n_lines_crowded = E[2]; I.n_lines_overflowing = E[0]; I.n_spilled_keys = E[4]; I.largest_line = (uint32_t)E[3];
+    if (getenv("MC_SKM_VERBOSE")) {
+        fprintf(stderr, "libmcclark: super-k-mer index: %llu entries in %llu records (%.2f per record); merge factor d:", (unsigned long long)B.sk_n_entries,
+                E[4], (double)B.sk_n_entries / (double)(E[4] ? E[4] : 1));
+        for (uint32_t t = 1; t <= 12; t++)
+            fprintf(stderr, " %u:%.3f%%/%.1fGB", t, 100.0 * (double)ev[t - 1][0] / (double)(n_fine / t), (double)((n_fine / t + ev[t - 1][1]) * 128ull) / 1e9);
+        fprintf(stderr, " -> d = %u, %u lines\n", d, n_lines);
+    }
+    index_abort(c);
+    int occ = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (mc::sk::sk_query_kernel<mc::mz::MZ_ALL, 0>), mc::BLOCK_THREADS, 0));
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+    if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
+    c->grid_blocks = occ * c->n_cu;
+    c->db_loaded = true;
+    return MC_OK;
+}
+
 // whole (shard of a) table resident on the device as raw arrays: one chunk per pass
 int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
                 uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end)
@@ -412,7 +637,7 @@ int relayout_mz(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16
 int relayout(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const uint16_t *d_labels,
              uint64_t n_keys, uint64_t shard_begin, uint64_t shard_end, bool fallback = false)
 {
-    if (!fallback && c->index_mode == 1 && mz_eligible(c, n_keys)) {
+    if (!fallback && c->index_mode >= 1 && mz_eligible(c, n_keys)) {
         const int rcm = relayout_mz(c, d_sz, d_keys, d_labels, n_keys, shard_begin, shard_end);
         if (rcm != MC_ENOMEM) return rcm;
         // not enough HBM for the minimizer lines: the direct table (about 3x slower to query) -- said aloud
@@ -582,7 +807,19 @@ int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64
     const uint64_t want = (n_groups + mc::WAVES_PER_BLOCK - 1) / mc::WAVES_PER_BLOCK;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)c->grid_blocks);
     const dim3 g(grid), b(mc::BLOCK_THREADS);
-    if (c->d_mz_lines) {
+    if (c->d_sk_lines) {
+        mc::sk::SkArgs m{};
+        m.q = a; m.lines = c->d_sk_lines; m.extra = c->d_sk_extra;
+        m.n_lines = c->sk_n_lines; m.part = c->mz_part; m.n_parts = c->mz_n_parts; m.m = c->mz_m;
+#define MC_SK_LAUNCH(SH)                                                                                                   \
+        do {                                                                                                               \
+            if (c->k == 31u) hipLaunchKernelGGL((mc::sk::sk_query_kernel<SH, 31>), g, b, 0, st, m);                       \
+            else if (c->k == 27u) hipLaunchKernelGGL((mc::sk::sk_query_kernel<SH, 27>), g, b, 0, st, m);                  \
+            else hipLaunchKernelGGL((mc::sk::sk_query_kernel<SH, 0>), g, b, 0, st, m);                                    \
+        } while (0)
+        if (c->info.n_parts > 1) MC_SK_LAUNCH(mc::mz::MZ_LINES); else MC_SK_LAUNCH(mc::mz::MZ_ALL);
+#undef MC_SK_LAUNCH
+    } else if (c->d_mz_lines) {
         mc::mz::MzArgs m{};
         m.q = a; m.lines = c->d_mz_lines; m.extra = c->d_mz_extra;
         m.n_lines = c->mz_n_local; m.part = c->mz_part; m.n_parts = c->mz_n_parts;
@@ -853,7 +1090,7 @@ uint32_t min_parts(uint64_t n_keys_total, uint32_t max_parts, uint64_t free_byte
     return 0;
 }
 
-bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode == 1 && mz_eligible(c, n_keys_total); }
+bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c->index_mode >= 1 && mz_eligible(c, n_keys_total); }
 
 // The files -> the index of every member, as a pipeline.  A reader thread fills one of two pinned chunk buffers
 // (parallel preads) while the other is in flight; each chunk is uploaded ONCE per device on that device's copy stream
@@ -1088,7 +1325,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
     c->div = mc::make_div(htsize);
     c->wide = wide;
-    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : 1;
+    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : strcmp(e, "skm") == 0 ? 2 : 1;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);

@@ -72,6 +72,14 @@ struct IndexBuild {
     size_t st_sz_cap = 0, st_key_cap = 0;                                                     // buckets / k-mers
     uint64_t n_extra = 0, n_spilled = 0, n_over = 0, n_crowded = 0;
     uint32_t longest = 0;
+    // the super-k-mer index (mc_skm.hpp): entries per FINE line (d_count), cursors of the second pass, offsets of the fine
+    // lines into the entries, the entries themselves
+    bool sk = false;
+    uint32_t sk_n_fine = 0;
+    uint32_t *d_cursor = nullptr, *d_off32 = nullptr;
+    uint64_t *d_blk_base = nullptr;
+    void *d_entries = nullptr;
+    uint64_t sk_n_entries = 0;
 };
 
 } // namespace mcint
@@ -103,7 +111,9 @@ struct mc_ctx {
     // locality-aware index (mc_minimizer.hpp): the default for k >= 16; MC_INDEX=lines
     // selects the direct bucket-line table instead (also the fallback when the minimizer
     // lines do not fit in HBM)
-    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines
+    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines, 2 = super-k-mer records (where k allows, else 1)
+    uint8_t *d_sk_lines = nullptr, *d_sk_extra = nullptr;      // super-k-mer index: lines of 8 slots, extra lines (chains)
+    uint32_t sk_n_lines = 0;
     uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;
     // The extra lines live BEHIND the primary lines in the same allocation whenever the room reserved for them at
     // mc_index_begin (the loader's estimate of their share) suffices: an allocation of its own, made after the first
