@@ -530,7 +530,9 @@ int sk_end(mc_ctx *c)
         return fail(MC_EINVAL, (failed & 4u) ? "bucket sizes do not sum to n_keys"
                                              : "super-k-mer index: the second pass held k-mers the first did not");
     }
-    double max_over = 0.01;
+    // (genome-shaped table, 5.5e9 k-mers: d = 7 / 4 / 3 -> 0.59 / 0.03 / 0.006 % of the lines overflow, 51 / 88 / 117 GB,
+    // 8.1 / 7.4 / 7.4 ms per 10 M reads: past 0.05 % the memory buys nothing)
+    double max_over = 0.0005;
     if (const char *e = getenv("MC_SKM_OVERFLOW")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) max_over = v; }
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
@@ -610,7 +612,9 @@ int sk_end(mc_ctx *c)
     int occ = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (mc::sk::sk_query_kernel<mc::mz::MZ_ALL, 0>), mc::BLOCK_THREADS, 0));
     if (occ < 1) occ = 1;
-    if (occ > 8) occ = 8;
+    // a persistent grid of 7 workgroups per CU although 8 fit (measured, genome-shaped table, one box, twice each:
+    // 8 / 7 / 6 / 5 / 4 per CU -> 7.47 / 6.68 / 6.73 / 6.77 / 7.14 ms per 10 M reads)
+    if (occ > 7) occ = 7;
     if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
     c->grid_blocks = occ * c->n_cu;
     c->db_loaded = true;

@@ -189,10 +189,9 @@ SK_HD void sk_merge(SkSlot &r, const SkSlot &e)
 // What a run of a read asks a record: the run's k-mers hold M at offsets o_lo .. o_hi, `lr` holds the o_hi bases
 // before M (low half, the base next to M in bits 1..0) and the FL - o_lo bases behind it (high half, the base next
 // to M in bits 31..30).  Returns how many of the run's k-mers the record holds (their label: r.d3).
-SK_HD uint32_t sk_match(const SkSlot &r, uint32_t kd0, uint32_t kd1, uint32_t o_lo, uint32_t o_hi, uint32_t lr)
+SK_HD uint32_t sk_match_flanks(uint32_t d1, uint32_t d2, uint32_t o_lo, uint32_t o_hi, uint32_t lr)
 {
-    if (((r.d0 ^ kd0) | ((r.d1 ^ kd1) & 0xFFFFFu)) != 0u || (r.d3 & SK_HDR)) return 0u;
-    const uint32_t x = r.d2 ^ lr;
+    const uint32_t x = d2 ^ lr;
     const uint32_t lmatch = sk_ctz((x & 0xFFFFu) | 0x10000u) >> 1;          // bases that agree, outward from M
     const uint32_t rmatch = sk_clz((x & 0xFFFF0000u) | 0x8000u) >> 1;
     const uint32_t lo = o_lo > (uint32_t)SK_FL - rmatch ? o_lo : (uint32_t)SK_FL - rmatch;
@@ -200,10 +199,18 @@ SK_HD uint32_t sk_match(const SkSlot &r, uint32_t kd0, uint32_t kd1, uint32_t o_
     if (hi < lo) return 0u;
     const uint32_t mask = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
 #ifdef __HIP_DEVICE_COMPILE__
-    return (uint32_t)__popc((r.d1 >> 20) & mask & 0x1FFu);
+    return (uint32_t)__popc((d1 >> 20) & mask & 0x1FFu);
 #else
-    return (uint32_t)__builtin_popcount((r.d1 >> 20) & mask & 0x1FFu);
+    return (uint32_t)__builtin_popcount((d1 >> 20) & mask & 0x1FFu);
 #endif
+}
+SK_HD bool sk_same_minimizer(const SkSlot &r, uint32_t kd0, uint32_t kd1)       // a record (not a header) of the run's minimizer
+{
+    return ((r.d0 ^ kd0) | ((r.d1 ^ kd1) & 0xFFFFFu)) == 0u && !(r.d3 & SK_HDR);
+}
+SK_HD uint32_t sk_match(const SkSlot &r, uint32_t kd0, uint32_t kd1, uint32_t o_lo, uint32_t o_hi, uint32_t lr)
+{
+    return sk_same_minimizer(r, kd0, kd1) ? sk_match_flanks(r.d1, r.d2, o_lo, o_hi, lr) : 0u;
 }
 
 // The descriptor of a run from what the kernel's front half leaves: the run's key K (hash | position of the m-mer
@@ -212,6 +219,10 @@ SK_HD uint32_t sk_match(const SkSlot &r, uint32_t kd0, uint32_t kd1, uint32_t o_
 struct SkRun { uint32_t kd0, kd1, o_lo, o_hi, lr; };
 SK_HD uint32_t sk_rev16(uint32_t e)          // reverse complement of 16 bases in a dword
 {
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint32_t r = __brev(e);                // bases in reverse order, the two bits of each swapped: swap them back, complement
+    return ~(((r >> 1) & 0x55555555u) | ((r << 1) & 0xAAAAAAAAu));
+#endif
     uint32_t v = ~e;
     v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
     v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
@@ -479,15 +490,26 @@ void sk_encode_kernel(const uint32_t *count0, const uint32_t *off32, const uint6
                 if (lane < n) { const uint4 v = *reinterpret_cast<const uint4 *>(src + lane); e = SkSlot{v.x, v.y, v.z, v.w}; }
                 const uint32_t n_rec = sk_form_records(e, n, lane);
                 if (n_rec != r_tot) { if (lane == 0) atomicOr(failed, 8u); continue; }        // the counting pass saw other records
+                // The records of one minimizer go into neighbouring slots: the query kernel's lanes hold slots q and q + 4 of a
+                // line, so up to four records of a minimizer are matched side by side (a genus of four behind one m-mer), and
+                // the layout no longer depends on the order the build's atomics ran in.  `at` = rank by (minimizer, formation order).
+                uint32_t at = 0;
+                {
+                    const uint64_t mine = ((uint64_t)(e.d1 & 0xFFFFFu) << 32) | e.d0;
+                    for (uint32_t j = 0; j < n_rec; j++) {
+                        const uint64_t other = ((uint64_t)(lane_bcast(e.d1, j) & 0xFFFFFu) << 32) | lane_bcast(e.d0, j);
+                        at += (other < mine || (other == mine && j < lane)) ? 1u : 0u;
+                    }
+                }
                 if (n_rec <= (uint32_t)SK_SLOTS) {
-                    if (lane < n_rec) first[lane] = make_uint4(e.d0, e.d1, e.d2, e.d3);
+                    if (lane < n_rec) first[at] = make_uint4(e.d0, e.d1, e.d2, e.d3);
                 } else {
                     // 7 records + header in the first line, the others in a linear chain; the header's Bloom word covers
                     // the minimizers of the chain's records
                     uint32_t w0 = 0, w1 = 0;
-                    if (lane < (uint32_t)(SK_SLOTS - 1)) first[lane] = make_uint4(e.d0, e.d1, e.d2, e.d3);
+                    if (lane < n_rec && at < (uint32_t)(SK_SLOTS - 1)) first[at] = make_uint4(e.d0, e.d1, e.d2, e.d3);
                     else if (lane < n_rec) {
-                        more[lane - (uint32_t)(SK_SLOTS - 1)] = make_uint4(e.d0, e.d1, e.d2, e.d3);
+                        more[at - (uint32_t)(SK_SLOTS - 1)] = make_uint4(e.d0, e.d1, e.d2, e.d3);
                         sk_bloom_bits(e.d0, &w0, &w1);
                     }
                     for (int o = 32; o > 0; o >>= 1) { w0 |= (uint32_t)__shfl_xor((int)w0, o, 64); w1 |= (uint32_t)__shfl_xor((int)w1, o, 64); }
@@ -539,6 +561,11 @@ struct SkArgs {
 };
 
 static constexpr int SK_RUNS = 32;            // runs matched per batch: 4 rounds of 8 lines, 8 lanes a line
+#ifdef MC_SK_MARK          // measurement builds only: markers in the instruction stream (tools/isa_sections.py counts between them)
+#define SK_MARK(n) asm volatile("s_nop " #n)
+#else
+#define SK_MARK(n) do { } while (0)
+#endif
 #ifndef MC_SK_MIN_WAVES
 #define MC_SK_MIN_WAVES 7
 #endif
@@ -554,8 +581,16 @@ static_assert(SK_LDS_KEYS % 16 == 0 && SK_LDS_DESC % 16 == 0 && SK_LDS_WAVE % 16
 __device__ __forceinline__ uint64_t sk_pos_key(uint64_t w, uint64_t rcw, uint32_t m, uint32_t pos2)
 {
     const uint64_t cw = mz::min_below_2_62(w, rcw);
-    const uint32_t low = w <= rcw ? (pos2 | 1u) : pos2;
-    return SK_ONE | sk_key_bits(cw, m) | low;
+    // sk_key_bits, packed by hand: the compiler builds the two halves with 64-bit shifts (8 operations for 3)
+    const uint32_t B = 2u * m - 32u;
+    const uint32_t a = (uint32_t)cw * 0x9E3779B1u;
+    const uint32_t h = (uint32_t)(cw >> 32) ^ (a >> (32u - B));
+    const uint32_t b = (a + __umul24(h, 0x85EBCBu)) * 0xC2B2AE35u;
+    uint32_t low;          // pos2 | (w <= rcw): the compare's carry added in
+    asm("v_cmp_le_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %3, vcc" : "=v"(low) : "v"(w), "v"(rcw), "v"(pos2) : "vcc");
+    const uint32_t khi = __builtin_amdgcn_alignbit(0x3FFu, b, 12);                 // 0x3FF00000 | b >> 12
+    const uint32_t klo = (b << 20) | ((h << (20u - B)) | low);
+    return ((uint64_t)khi << 32) | klo;
 }
 
 // SHARD: mz::MZ_ALL (the whole table) or mz::MZ_LINES (the k-mers of 1/G of the minimizers); KC: k compiled in (31, 27) or 0
@@ -672,16 +707,20 @@ void sk_query_kernel(const SkArgs A)
 
             // fold what the lanes found -- `cnt` k-mers of target `lab` each -- into the read's accumulator: lane j holds the
             // j-th distinct target.  Counts are at most 9: four lane masks, one per bit, and popcounts on the scalar side.
-            auto fold = [&](uint32_t lab, uint32_t cnt) {
+            auto fold = [&](uint32_t lab, uint32_t cnt, auto wide_c) {
+                constexpr bool WIDE = decltype(wide_c)::value;            // counts up to 63 (the rounds of a batch added up), else up to 15
                 uint64_t many = mask_ne(cnt, 0u);
                 if (many == 0) return;
                 const uint64_t b1 = mask_ne(cnt & 1u, 0u), b2 = mask_ne(cnt & 2u, 0u), b4 = mask_ne(cnt & 4u, 0u), b8 = mask_ne(cnt & 8u, 0u);
+                uint64_t b16 = 0, b32 = 0;
+                if constexpr (WIDE) { b16 = mask_ne(cnt & 16u, 0u); b32 = mask_ne(cnt & 32u, 0u); }
                 while (many) {
                     const uint32_t t = lane_bcast(lab, (uint32_t)(__ffsll((unsigned long long)many) - 1));
                     const uint64_t same = mask_eq_s(lab, t) & many;
                     many &= ~same;
-                    const uint32_t c = (uint32_t)__popcll(same & b1) + 2u * (uint32_t)__popcll(same & b2)
-                                     + 4u * (uint32_t)__popcll(same & b4) + 8u * (uint32_t)__popcll(same & b8);
+                    uint32_t c = (uint32_t)__popcll(same & b1) + 2u * (uint32_t)__popcll(same & b2)
+                               + 4u * (uint32_t)__popcll(same & b4) + 8u * (uint32_t)__popcll(same & b8);
+                    if constexpr (WIDE) c += 16u * (uint32_t)__popcll(same & b16) + 32u * (uint32_t)__popcll(same & b32);
                     const uint64_t ex = __ballot(acc_t == t);
                     if (ex) {
                         if (acc_t == t) acc_c += c;
@@ -707,6 +746,7 @@ void sk_query_kernel(const SkArgs A)
                 const uint32_t nk = plen - k + 1u;
 
                 for (uint32_t base = 0; base < nk; base += 64u * MZ_NS) {
+                    SK_MARK(9);
                     // (1) lane l: the k-mers at positions base + 2l and base + 2l + 1, the keys of the m-mers that start there
                     //     (hash | position mod 16 | strand), the ends of the k-mers (first 8 bases | last 8 bases)
                     const bool last_step = base + 64u * MZ_NS >= nk;
@@ -770,6 +810,7 @@ void sk_query_kernel(const SkArgs A)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    SK_MARK(10);
                     // (2) window minimum = the k-mer's key, (3) runs of equal keys, numbered
                     uint32_t n_runs;
                     uint64_t K[MZ_NS];
@@ -806,6 +847,7 @@ void sk_query_kernel(const SkArgs A)
 
                     for (uint32_t rb = 0; rb < n_runs; rb += SK_RUNS) {
                         const uint32_t nb = n_runs - rb < (uint32_t)SK_RUNS ? n_runs - rb : (uint32_t)SK_RUNS;
+                        SK_MARK(11);
                         // (4) the runs of this batch publish key and first / last position ...
 #pragma unroll
                         for (int s = 0; s < MZ_NS; s++) {
@@ -820,6 +862,7 @@ void sk_query_kernel(const SkArgs A)
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+                        SK_MARK(12);
                         // ... (5) and lane r < nb turns run r into what the records are asked: key hash, offsets, flanks, line
                         {
                             const uint32_t r = opaque(lane) & (uint32_t)(SK_RUNS - 1);
@@ -829,75 +872,118 @@ void sk_query_kernel(const SkArgs A)
                             const SkRun R = sk_run(Kr, base + raw[2], base + raw[3], ea, eb);
                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                             __builtin_amdgcn_wave_barrier();
-                            if (lane < (uint32_t)SK_RUNS) desc[r] = u32x4{R.kd0, R.kd1 | (R.o_lo << 20) | (R.o_hi << 24), R.lr, sk_line_of(Kr, A.n_lines)};
+                            // (entries behind the batch's last run: the last run's line -- fetched anyway -- and an empty range of
+                            // offsets: the lane groups past the last run match nothing, without a test)
+                            const uint32_t ln = sk_line_of(Kr, A.n_lines);
+                            const uint32_t ln_last = lane_bcast(ln, nb - 1u);
+                            const bool real = __builtin_amdgcn_inverse_ballot_w64(mask_lt_s(r, nb));
+                            if (lane < (uint32_t)SK_RUNS)
+                                desc[r] = u32x4{R.kd0, real ? (R.kd1 | (R.o_lo << 20) | (R.o_hi << 24)) : (15u << 20), R.lr, real ? ln : ln_last};
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        // (6) 8 lanes fetch the line of a run, 16 bytes = one slot each; all rounds in flight before any is used
-                        u32x4 v[SK_RUNS / 8];
+                        SK_MARK(13);
+                        // (6) FOUR lanes fetch the line of a run, two slots each (lane q of the four: slots q and q + 4 -- the build
+                        //     puts the records of one minimizer into neighbouring slots, so they sit in different lanes); 16 runs a
+                        //     round, every round in flight before any is used
+                        constexpr int ROUNDS = SK_RUNS / 16;
+                        u32x4 va[ROUNDS], vb[ROUNDS];
                         const uint32_t lf = opaque(lane);
                         const uint32_t last = nb - 1u;
+                        const uint64_t lane_base = (uint64_t)(uintptr_t)A.lines + (lf & 3u) * 16u;
 #pragma unroll
-                        for (int rd = 0; rd < SK_RUNS / 8; rd++) {
-                            if (8u * rd < nb) {
-                                const uint32_t j = 8u * rd + (lf >> 3);
-                                const uint32_t ln = reinterpret_cast<const uint32_t *>(desc + (j < last ? j : last))[3];
-                                v[rd] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(A.lines + ((uint64_t)ln << 7) + (lf & 7u) * 16u));
+                        for (int rd = 0; rd < ROUNDS; rd++) {
+                            if (16u * rd < nb) {
+                                const uint32_t j = 16u * rd + (lf >> 2);
+#ifdef MC_SK_DEBUG_WINDOW      // measurement builds only (WRONG results): every fetch inside a cache-resident window of lines
+                                const uint32_t ln = reinterpret_cast<const uint32_t *>(desc + j)[3] & (uint32_t)(MC_SK_DEBUG_WINDOW - 1);
+#else
+                                const uint32_t ln = reinterpret_cast<const uint32_t *>(desc + j)[3];
+#endif
+                                uint64_t addr;              // lane_base + ln * 128 in one operation
+                                asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(addr) : "v"(ln), "s"(128u), "v"(lane_base) : "vcc");
+                                va[rd] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>((uintptr_t)addr));
+                                vb[rd] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>((uintptr_t)addr + 64u));
                             }
                         }
-                        // (7) every lane matches its slot against its run
-                        uint64_t hdrs = 0;
+                        SK_MARK(14);
+                        // (7) a lane looks for the run's minimizer in its two slots and works the flanks out for the one that has it
+                        //     (both: a second turn, rare); what a lane finds over the rounds is added up as long as it is one target's
+                        //     and folded into the read's accumulator once per batch
+                        uint32_t lab_a = 0u, cnt_a = 0u, hdr_any = 0u;
+                        auto gather = [&](uint32_t lab, uint32_t c) {
+                            if ((mask_ne(c, 0u) & mask_ne(cnt_a, 0u) & mask_ne(lab, lab_a)) != 0) { fold(lab_a, cnt_a, std::true_type{}); cnt_a = 0u; }
+                            lab_a = c ? lab : lab_a;
+                            cnt_a += c;
+                        };
 #pragma unroll
-                        for (int rd = 0; rd < SK_RUNS / 8; rd++) {
-                            if (8u * rd < nb) {
-                                const uint32_t j = 8u * rd + (lf >> 3);
+                        for (int rd = 0; rd < ROUNDS; rd++) {
+                            if (16u * rd < nb) {
+                                const uint32_t j = 16u * rd + (lf >> 2);
+                                const u32x4 dq = desc[j];
+                                const uint32_t kd1 = dq[1] & 0xFFFFFu, o_lo = (dq[1] >> 20) & 15u, o_hi = (dq[1] >> 24) & 15u;
+                                const uint64_t ma = mask_eq_s((va[rd][0] ^ dq[0]) | ((va[rd][1] ^ kd1) & 0xFFFFFu), 0u);
+                                const uint64_t mb = mask_eq_s((vb[rd][0] ^ dq[0]) | ((vb[rd][1] ^ kd1) & 0xFFFFFu) | (vb[rd][3] & SK_HDR), 0u);
+                                if ((ma | mb) != 0) {
+                                    const bool in_a = __builtin_amdgcn_inverse_ballot_w64(ma);
+                                    const uint32_t e1 = in_a ? va[rd][1] : vb[rd][1], e2 = in_a ? va[rd][2] : vb[rd][2], e3 = in_a ? va[rd][3] : vb[rd][3];
+                                    uint32_t c = sk_match_flanks(e1, e2, o_lo, o_hi, dq[2]);
+                                    c = __builtin_amdgcn_inverse_ballot_w64(ma | mb) ? c : 0u;
+                                    gather(e3 & 0xFFFFu, c);
+                                    if ((ma & mb) != 0) {
+                                        uint32_t c2 = sk_match_flanks(vb[rd][1], vb[rd][2], o_lo, o_hi, dq[2]);
+                                        c2 = __builtin_amdgcn_inverse_ballot_w64(ma & mb) ? c2 : 0u;
+                                        gather(vb[rd][3] & 0xFFFFu, c2);
+                                    }
+                                }
+                                hdr_any |= vb[rd][3];
+                            }
+                        }
+                        SK_MARK(15);
+                        fold(lab_a, cnt_a, std::true_type{});
+                        SK_MARK(8);
+                        if ((mask_ne(hdr_any & SK_HDR, 0u) & 0x8888888888888888ull) != 0) {
+                            // Rare: some line of the batch has extra lines (its slot 7 -- the second slot of a group's lane 3 -- is a header)
+#pragma unroll
+                            for (int rd = 0; rd < ROUNDS; rd++) {
+                                if (16u * rd >= nb) continue;
+                                const uint32_t j = 16u * rd + (lf >> 2);
                                 const u32x4 dq = desc[j < last ? j : last];
                                 const uint64_t valid = mask_lt_s(j, nb);
-                                const SkSlot slot{v[rd][0], v[rd][1], v[rd][2], v[rd][3]};
-                                uint32_t c = sk_match(slot, dq[0], dq[1] & 0xFFFFFu, (dq[1] >> 20) & 15u, (dq[1] >> 24) & 15u, dq[2]);
-                                if (!__builtin_amdgcn_inverse_ballot_w64(valid)) c = 0u;
-                                fold(slot.d3 & 0xFFFFu, c);
-                                const uint64_t h = mask_ne(slot.d3 & SK_HDR, 0u) & valid & 0x8080808080808080ull;
-                                hdrs |= h;
-                                if (h != 0) {
-                                    // Rare: the line has extra lines.  The header (slot 7) goes to the 8 lanes of its group.
-                                    const int src = (int)((lf | 7u) << 2);
-                                    const uint32_t h0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)slot.d0), h1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)slot.d1);
-                                    const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)slot.d2), h3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)slot.d3);
-                                    const bool has = (h3 & SK_HDR) != 0u && __builtin_amdgcn_inverse_ballot_w64(valid);
-                                    const uint32_t o_lo = (dq[1] >> 20) & 15u, o_hi = (dq[1] >> 24) & 15u;
-                                    const uint8_t *xl = arg_extra() + (lf & 7u) * 16u;
-                                    // a linear chain: every line of it, when the Bloom word knows the run's minimizer
-                                    const uint32_t n_lin = has && sk_bloom_pass(h0, h1, dq[0]) ? (h3 & 0xFFu) : 0u;
-                                    for (uint32_t i = 0; __ballot(i < n_lin) != 0; i++) {
-                                        uint32_t cc = 0u, lab = 0u;
-                                        if (i < n_lin) {
-                                            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(xl + ((uint64_t)(h2 + i) << 7)));
-                                            cc = sk_match(SkSlot{x[0], x[1], x[2], x[3] & 0xFFFFu}, dq[0], dq[1] & 0xFFFFFu, o_lo, o_hi, dq[2]);
-                                            lab = x[3] & 0xFFFFu;
-                                        }
-                                        fold(lab, cc);
+                                if ((mask_ne(vb[rd][3] & SK_HDR, 0u) & valid & 0x8888888888888888ull) == 0) continue;
+                                // the header goes to the 4 lanes of its group
+                                const int src = (int)((lf | 3u) << 2);
+                                const uint32_t h0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)vb[rd][0]), h1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)vb[rd][1]);
+                                const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)vb[rd][2]), h3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)vb[rd][3]);
+                                const bool has = (h3 & SK_HDR) != 0u && __builtin_amdgcn_inverse_ballot_w64(valid);
+                                const uint32_t kd1 = dq[1] & 0xFFFFFu, o_lo = (dq[1] >> 20) & 15u, o_hi = (dq[1] >> 24) & 15u;
+                                const uint8_t *xl = arg_extra() + (lf & 3u) * 16u;
+                                // one line of a chain, two slots a lane, matched against offsets lo .. hi of the run
+                                auto chain_line = [&](bool on, uint32_t line, uint32_t lo, uint32_t hi) {
+                                    uint32_t ca = 0u, cb = 0u, la = 0u, lb = 0u;
+                                    if (on) {
+                                        const u32x4 xa = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(xl + ((uint64_t)line << 7)));
+                                        const u32x4 xb = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(xl + ((uint64_t)line << 7) + 64u));
+                                        ca = sk_match(SkSlot{xa[0], xa[1], xa[2], xa[3] & 0xFFFFu}, dq[0], kd1, lo, hi, dq[2]);
+                                        cb = sk_match(SkSlot{xb[0], xb[1], xb[2], xb[3] & 0xFFFFu}, dq[0], kd1, lo, hi, dq[2]);
+                                        la = xa[3] & 0xFFFFu; lb = xb[3] & 0xFFFFu;
                                     }
-                                    // hashed chains: k-mer by k-mer, the chain line the k-mer's own hash picks and the ones behind it
-                                    const uint32_t sl = has ? (h3 >> 8) & 0xFFu : 0u, probes = (h3 >> 16) & 15u;
-                                    for (uint32_t t = 0; __ballot(sl != 0u && o_lo + t <= o_hi) != 0; t++) {
-                                        const uint32_t o = o_lo + t;
-                                        const bool on = sl != 0u && o <= o_hi;
-                                        const uint32_t hh = on ? sk_entry_hash(dq[0], o, sk_lr_of(dq[2], o)) >> (32u - sl) : 0u;
-                                        for (uint32_t pr = 0; __ballot(on && pr < probes) != 0; pr++) {
-                                            uint32_t cc = 0u, lab = 0u;
-                                            if (on && pr < probes) {
-                                                const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(xl + ((uint64_t)(h2 + hh + pr) << 7)));
-                                                cc = sk_match(SkSlot{x[0], x[1], x[2], x[3] & 0xFFFFu}, dq[0], dq[1] & 0xFFFFFu, o, o, dq[2]);
-                                                lab = x[3] & 0xFFFFu;
-                                            }
-                                            fold(lab, cc);
-                                        }
-                                    }
+                                    fold(la, ca, std::false_type{});
+                                    fold(lb, cb, std::false_type{});
+                                };
+                                // a linear chain: every line of it, when the Bloom word knows the run's minimizer
+                                const uint32_t n_lin = has && sk_bloom_pass(h0, h1, dq[0]) ? (h3 & 0xFFu) : 0u;
+                                for (uint32_t i = 0; __ballot(i < n_lin) != 0; i++) chain_line(i < n_lin, h2 + i, o_lo, o_hi);
+                                // hashed chains: k-mer by k-mer, the chain line the k-mer's own hash picks and the ones behind it
+                                const uint32_t sl = has ? (h3 >> 8) & 0xFFu : 0u, probes = (h3 >> 16) & 15u;
+                                for (uint32_t t = 0; __ballot(sl != 0u && o_lo + t <= o_hi) != 0; t++) {
+                                    const uint32_t o = o_lo + t;
+                                    const bool on = sl != 0u && o <= o_hi;
+                                    const uint32_t hh = on ? sk_entry_hash(dq[0], o, sk_lr_of(dq[2], o)) >> (32u - sl) : 0u;
+                                    for (uint32_t pr = 0; __ballot(on && pr < probes) != 0; pr++) chain_line(on && pr < probes, h2 + hh + pr, o, o);
                                 }
                             }
                         }
-                        (void)hdrs;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
