@@ -503,7 +503,14 @@ def extra_genomes(args, torch, np, dev, dev_index, _genomes):
     genomes_h = genomes.cpu()
     del genomes
     torch.cuda.empty_cache()
+    # this table gets the index MC_INDEX=auto picks for it (super-k-mer records: its k-mers come in runs around shared
+    # minimizers); the headline table keeps whatever the run was started with
+    saved = os.environ.get("MC_INDEX")
+    if saved is None:
+        os.environ["MC_INDEX"] = "auto"
     db = CuClarkDB(k=k, numBatches=1, numTargets=T, device=dev_index, htsize=ht, maxhits=MAXHITS)
+    if saved is None:
+        os.environ.pop("MC_INDEX", None)
     try:
         db.read_chunks(lambda: host, n_keys, device=False)
         info = db.db_info()
@@ -527,7 +534,9 @@ def extra_genomes(args, torch, np, dev, dev_index, _genomes):
         kern = sum(a.elapsed_time(b) for a, b in ev) / steps
         res = {"value": round(n_reads * steps / dt / 1e6, 2), "unit": "Mreads/s", "kernel_ms": round(kern, 4), "steps": steps,
                "reads_per_step": n_reads, "n_kmers_db": n_keys,
-               "index": {"lines": info["line_end"] - info["line_begin"], "extra_lines": info["n_extra_lines"],
+               "index": {"kind": {1: "minimizer", 2: "skm"}.get(info["index_kind"], "lines"),
+                         "hbm_bytes_per_kmer": round(info["device_bytes"] / max(1, n_keys), 2),
+                         "lines": info["line_end"] - info["line_begin"], "extra_lines": info["n_extra_lines"],
                          "kmers_per_line": round(n_keys / max(1, info["n_lines"]), 2),
                          "lines_overflowing_frac": round(info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]), 5),
                          "lines_crowded": info["n_lines_crowded"], "largest_line_kmers": info["largest_line"], "hbm_bytes": info["device_bytes"]},

@@ -103,6 +103,7 @@ void index_abort(mc_ctx *c)
     if (c->build.d_off32) (void)hipFree(c->build.d_off32);
     if (c->build.d_blk_base) (void)hipFree(c->build.d_blk_base);
     if (c->build.d_entries) (void)hipFree(c->build.d_entries);
+    if (c->build.d_count_mz) (void)hipFree(c->build.d_count_mz);
     c->build = mcint::IndexBuild();
 }
 
@@ -117,6 +118,34 @@ int sk_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts);
 int sk_next_pass(mc_ctx *c);
 int sk_end(mc_ctx *c);
 bool use_sk(const mc_ctx *c) { return c->index_mode == 2 && mc::sk::sk_supported(c->k); }
+
+bool use_both(const mc_ctx *c) { return c->index_mode == 3 && mc::sk::sk_supported(c->k); }
+
+// the lines of the minimizer index (+ the room reserved behind them), filled with "empty"
+int mz_alloc_lines(mc_ctx *c)
+{
+    const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
+    // MC_MZ_ALLOC_LIMIT (bytes): a cap on the lines of one context -- a card shared with other tenants, and how the tests
+    // reach the "does not fit" paths (the fallback to the bucket-line table, a group that cuts the table into more parts)
+    if (const char *e = getenv("MC_MZ_ALLOC_LIMIT")) {
+        const uint64_t lim = strtoull(e, nullptr, 10);
+        if (lim && (uint64_t)lbytes > lim)
+            return fail(MC_ENOMEM, "minimizer lines of " + std::to_string(lbytes) + " bytes exceed MC_MZ_ALLOC_LIMIT");
+    }
+    // room for the extra lines behind the primary lines, in the same allocation (mc_internal.hpp): the share the
+    // loader's budget assumes for this fill (index_bytes), which a genome-shaped table stays below
+    uint64_t reserve = c->build.mz_reserve;
+    if (hipMalloc(&c->d_mz_lines, lbytes + (size_t)reserve * mc::mz::MZ_LINE) != hipSuccess) {
+        (void)hipGetLastError();
+        reserve = 0;                                            // a tight card: the lines alone, the extra lines where they fit
+        c->d_mz_lines = nullptr;
+        if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess) { (void)hipGetLastError(); c->d_mz_lines = nullptr; }
+    }
+    c->mz_extra_reserved = reserve;
+    if (!c->d_mz_lines) return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
+    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, c->streams[0]));
+    return MC_OK;
+}
 
 int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts)
 {
@@ -144,40 +173,30 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     if (want == 0)
         return fail(MC_EINVAL, "minimizer index: " + std::to_string(n_keys_total) + " k-mers at " + std::to_string(per_line) +
                                " per line over " + std::to_string(n_parts) + " part(s) need more than 2^32 lines per part");
+    const bool both = use_both(c);
+    if (both) {          // the super-k-mer build's counters first (it resets the context), the minimizer index's next to them
+        const int rc = sk_begin(c, n_keys_total, part, n_parts);
+        if (rc != MC_OK) return rc;
+        c->build.both = true;
+    }
     c->mz_n_local = (uint32_t)want;
     c->mz_part = part; c->mz_n_parts = n_parts;
     c->mz_m = mc::mz::mmer_len(c->k);
     c->info = mc_db_info{};
     c->info.part = part; c->info.n_parts = n_parts;
-    const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
-    // MC_MZ_ALLOC_LIMIT (bytes): a cap on the lines of one context -- a card shared with other tenants, and how the tests
-    // reach the "does not fit" paths (the fallback to the bucket-line table, a group that cuts the table into more parts)
-    if (const char *e = getenv("MC_MZ_ALLOC_LIMIT")) {
-        const uint64_t lim = strtoull(e, nullptr, 10);
-        if (lim && (uint64_t)lbytes > lim)
-            return fail(MC_ENOMEM, "minimizer lines of " + std::to_string(lbytes) + " bytes exceed MC_MZ_ALLOC_LIMIT");
-    }
-    // room for the extra lines behind the primary lines, in the same allocation (mc_internal.hpp): the share the
-    // loader's budget assumes for this fill (index_bytes), which a genome-shaped table stays below
-    uint64_t reserve = (uint64_t)((double)c->mz_n_local * mcint::extra_share(per_line)) + 64;
-    if (getenv("MC_MZ_NO_RESERVE")) reserve = 0;
-    if (hipMalloc(&c->d_mz_lines, lbytes + (size_t)reserve * mc::mz::MZ_LINE) != hipSuccess) {
-        (void)hipGetLastError();
-        reserve = 0;                                            // a tight card: the lines alone, the extra lines where they fit
-        c->d_mz_lines = nullptr;
-        if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess) { (void)hipGetLastError(); c->d_mz_lines = nullptr; }
-    }
-    c->mz_extra_reserved = reserve;
-    if (!c->d_mz_lines ||
-        hipMalloc(&c->build.d_count, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess ||
-        hipMalloc(&c->build.d_failed, 4) != hipSuccess) {
-        (void)hipGetLastError();
-        free_db(c); index_abort(c);
-        return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
-    }
+    c->build.mz_per_line = per_line;
+    c->build.mz_reserve = getenv("MC_MZ_NO_RESERVE") ? 0 : (uint64_t)((double)c->mz_n_local * mcint::extra_share(per_line)) + 64;
     hipStream_t st = c->streams[0];
-    HIPCHK(hipMemsetAsync(c->build.d_count, 0, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4, st));
-    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, st));
+    uint32_t **cnt = both ? &c->build.d_count_mz : &c->build.d_count;
+    // (MC_INDEX=auto: the lines are allocated between the passes, once it is known which index they are for)
+    int rc = both ? (int)MC_OK : mz_alloc_lines(c);
+    if (rc == MC_OK && (hipMalloc(cnt, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess ||
+                        (!c->build.d_failed && hipMalloc(&c->build.d_failed, 4) != hipSuccess))) {
+        (void)hipGetLastError();
+        rc = fail(MC_ENOMEM, "not enough HBM for the line counters of the minimizer index");
+    }
+    if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; return rc; }
+    HIPCHK(hipMemsetAsync(*cnt, 0, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4, st));
     HIPCHK(hipMemsetAsync(c->build.d_failed, 0, 4, st));
     c->build.open = true; c->build.pass = 0; c->build.n_keys_total = n_keys_total;
     return MC_OK;
@@ -208,6 +227,13 @@ int index_add_typed(mc_ctx *c, const uint8_t *d_sz, const void *d_keys, const ui
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(mc::mz::mz_scan_blocks_kernel, dim3(1), dim3(256), 0, st, B.d_blk, nblk, B.d_koff, n_keys, B.d_failed);
     HIPCHK(hipGetLastError());
+    if (B.both && c->build.pass == 0) {
+        hipLaunchKernelGGL((mc::mz::mz_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
+                           static_cast<const key_t *>(d_keys), d_labels, nb, n_keys, b0, c->htsize, B.d_koff, c->k, c->mz_m,
+                           c->mz_part, c->mz_n_parts, c->mz_n_local, B.d_count_mz,
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, B.d_failed);
+        HIPCHK(hipGetLastError());
+    }
     if (B.sk) {
         if (c->build.pass == 0)
             hipLaunchKernelGGL((mc::sk::sk_build_kernel<0, WIDE>), dim3(nblk), dim3(mc::RL_THREADS), 0, st, d_sz,
@@ -303,6 +329,39 @@ int index_add_host(mc_ctx *c, const uint8_t *sz, const void *keys, int key_bytes
 int index_next_pass(mc_ctx *c)
 {
     if (!c->build.open || c->build.pass != 0) return fail(MC_ESTATE, "mc_index_next_pass out of order");
+    if (c->build.both) {
+        // How do the k-mers clump around their minimizers?  Isolated k-mers spread over the fine lines like a Poisson
+        // process (variance / mean of the counts = 1); the k-mers of genomes come as runs that share a minimizer, related
+        // genomes put several runs behind one (the genome-shaped table: ~20).  Clumped tables get records, the others lines.
+        mcint::IndexBuild &B = c->build;
+        Scope tmp;
+        unsigned long long *d_mom = nullptr, mom[2] = {0, 0};
+        TMP_MALLOC(tmp, d_mom, 16);
+        HIPCHK(hipMemsetAsync(d_mom, 0, 16, c->streams[0]));
+        const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)B.sk_n_fine + 255) / 256, (uint64_t)c->n_cu * 8));
+        hipLaunchKernelGGL(mc::sk::sk_moments_kernel, dim3(g), dim3(256), 0, c->streams[0], B.d_count, (uint64_t)B.sk_n_fine, d_mom);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(mom, d_mom, 16, hipMemcpyDeviceToHost, c->streams[0]));
+        HIPCHK(hipStreamSynchronize(c->streams[0]));
+        const double nf = (double)B.sk_n_fine, mean = (double)mom[0] / nf;
+        const double fano = mean > 0.0 ? ((double)mom[1] / nf - mean * mean) / mean : 0.0;
+        double need = 2.5;
+        if (const char *e = getenv("MC_AUTO_CLUMP")) { const double v = atof(e); if (v > 0.0) need = v; }
+        const bool records = fano >= need;
+        if (getenv("MC_SKM_VERBOSE"))
+            fprintf(stderr, "libmcclark: MC_INDEX=auto: variance / mean of the k-mers per fine line %.2f -> %s\n", fano, records ? "super-k-mer records" : "minimizer lines");
+        B.both = false;
+        if (records) {
+            (void)hipFree(B.d_count_mz); B.d_count_mz = nullptr;
+            c->mz_n_local = 0;
+        } else {
+            (void)hipFree(B.d_count); (void)hipFree(B.d_cursor); (void)hipFree(B.d_off32); (void)hipFree(B.d_blk_base);
+            B.d_count = B.d_count_mz; B.d_count_mz = nullptr; B.d_cursor = nullptr; B.d_off32 = nullptr; B.d_blk_base = nullptr;
+            B.sk = false;
+            const int rc = mz_alloc_lines(c);
+            if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; return rc; }
+        }
+    }
     if (c->build.sk) return sk_next_pass(c);
     hipStream_t st = c->streams[0];
     const uint64_t n = c->mz_n_local;
@@ -548,7 +607,7 @@ int sk_end(mc_ctx *c)
             if ((nl + ev[t - 1][1]) * (uint64_t)SK_LINE + nl * 8 + (3ull << 30) <= (uint64_t)fr) d = t;
         }
     }
-    if (c->fill_hint >= 1.0) d = (uint32_t)c->fill_hint;           // a group loader: one layout for all members
+    if (c->sk_d_hint >= 1 && c->sk_d_hint <= 12) d = c->sk_d_hint;       // a group loader: one layout for all members
     if (const char *e = getenv("MC_SKM_D")) { const int v = atoi(e); if (v >= 1 && v <= 12) d = (uint32_t)v; }
     if (d == 0 || d > 12) { free_db(c); index_abort(c); return fail(MC_ENOMEM, "super-k-mer index: the lines do not fit the free HBM at any merge factor"); }
     const uint32_t n_lines = n_fine / d;
@@ -587,7 +646,7 @@ int sk_end(mc_ctx *c)
         free_db(c); index_abort(c);
         return fail(MC_EINVAL, (failed & 1u) ? "super-k-mer index: a hashed chain overflowed" : "internal: the records of a line came out differently the second time");
     }
-    c->sk_n_lines = n_lines;
+    c->sk_n_lines = n_lines; c->sk_d = d;
     mc_db_info &I = c->info;
     I.htsize = c->htsize;
     I.shard_begin = B.bucket_lo == ~0ull ? 0 : B.bucket_lo;
@@ -1248,6 +1307,9 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
         reader.join();
         for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
             rc = set_dev(ctxs[i]);
+            // (super-k-mer records: the first member's merge factor is everybody's -- the parts of one table must agree
+            // on the line count, and replicas may as well)
+            if (pass == 1) ctxs[i]->sk_d_hint = i ? ctxs[0]->sk_d : 0;
             if (rc == MC_OK) rc = pass == 0 ? index_next_pass(ctxs[i]) : index_end(ctxs[i]);
         }
     }
@@ -1329,7 +1391,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
     c->div = mc::make_div(htsize);
     c->wide = wide;
-    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : strcmp(e, "skm") == 0 ? 2 : 1;
+    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : strcmp(e, "skm") == 0 ? 2 : strcmp(e, "auto") == 0 ? 3 : 1;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);

@@ -75,6 +75,11 @@ struct IndexBuild {
     // the super-k-mer index (mc_skm.hpp): entries per FINE line (d_count), cursors of the second pass, offsets of the fine
     // lines into the entries, the entries themselves
     bool sk = false;
+    // MC_INDEX=auto: the first pass counts for BOTH indexes; mc_index_next_pass looks at how the k-mers clump around their
+    // minimizers (the counts of the fine lines) and goes on with one of them
+    bool both = false;
+    uint32_t *d_count_mz = nullptr;
+    uint64_t mz_reserve = 0; double mz_per_line = 0.0;
     uint32_t sk_n_fine = 0;
     uint32_t *d_cursor = nullptr, *d_off32 = nullptr;
     uint64_t *d_blk_base = nullptr;
@@ -111,7 +116,10 @@ struct mc_ctx {
     // locality-aware index (mc_minimizer.hpp): the default for k >= 16; MC_INDEX=lines
     // selects the direct bucket-line table instead (also the fallback when the minimizer
     // lines do not fit in HBM)
-    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines, 2 = super-k-mer records (where k allows, else 1)
+    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines, 2 = super-k-mer records (where k allows, else 1),
+                                       // 3 = minimizer lines or super-k-mer records, whichever suits the table (where k allows, else 1)
+    uint32_t sk_d = 0;                 // merge factor the super-k-mer index was built with ...
+    uint32_t sk_d_hint = 0;            // ... and the one a group loader prescribes (all members: one layout; 0 = choose here)
     uint8_t *d_sk_lines = nullptr, *d_sk_extra = nullptr;      // super-k-mer index: lines of 8 slots, extra lines (chains)
     uint32_t sk_n_lines = 0;
     uint8_t *d_mz_lines = nullptr, *d_mz_extra = nullptr;

@@ -359,6 +359,17 @@ void sk_scan_blocks_kernel(const uint32_t *blk, uint32_t n, uint64_t *off)
     if (threadIdx.x == 0) off[n] = tot;
 }
 
+// sum and sum of squares of the counters (MC_INDEX=auto: how the k-mers clump)
+static __global__ __launch_bounds__(256)
+void sk_moments_kernel(const uint32_t *cnt, uint64_t n, unsigned long long *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const unsigned long long v = cnt[i]; s1 += v; s2 += v * v; }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if ((threadIdx.x & 63) == 0 && s1) { atomicAdd(&out[0], s1); atomicAdd(&out[1], s2); }
+}
+
 // One wave, up to 64 entries (lane i holds entry i): first fit into records; lane r < n_rec ends with record r.
 __device__ __forceinline__ uint32_t sk_form_records(SkSlot &e, uint32_t n, uint32_t lane)
 {

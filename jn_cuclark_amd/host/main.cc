@@ -200,7 +200,7 @@ struct Classifier {
             if (gi.mode == MC_GROUP_SHARDS) std::cerr << ": " << gi.n_shards << " parts x " << gi.n_groups << " groups";
             std::cerr << ", peer access " << (gi.peer_access ? "yes" : "no") << ")\n";
             std::cerr << "Total DB size in HBM:\t" << gi.device_bytes_max / 1000000 / 1000.0 << " GB per device (" << gi.n_keys
-                      << " k-mers, " << (info.index_kind == MC_INDEX_MINIMIZER ? "minimizer index" : "bucket-line table")
+                      << " k-mers, " << (info.index_kind == MC_INDEX_MINIMIZER ? "minimizer index" : info.index_kind == MC_INDEX_SUPERKMER ? "super-k-mer index" : "bucket-line table")
                       << (info.index_fallback ? " [fallback: the minimizer index did not fit]" : "") << ", " << info.line_bytes
                       << "-byte lines)\n";
             std::cerr << "DB loaded.\n";

@@ -206,3 +206,42 @@ def test_genome_shaped_table_every_read_against_the_oracle(gpu, oracle):
     assert info["n_spilled_keys"] * 3 < n_keys
     assert info["device_bytes"] < 25 * n_keys
     assert info["n_lines_overflowing"] < 0.03 * (info["line_end"] - info["line_begin"])
+
+
+def test_auto_picks_records_for_genomes_and_lines_for_isolated_kmers(gpu, oracle, monkeypatch):
+    """MC_INDEX=auto counts for both indexes in the first build pass and looks at how the k-mers clump around their
+    minimizers: a table made of genomes gets super-k-mer records, a table of isolated random k-mers minimizer lines"""
+    monkeypatch.setenv("MC_INDEX", "auto")
+    k = 31
+    genomes, sz, ky, lb = small_db(k=k, glen=6000)
+    codes, _ = synth.sample_reads(genomes, 2000, 150, seed=12)
+    rp, con = synth.pack_uniform(codes)
+    _check(gpu, oracle, k, sz, ky, lb, rp, con, 6, expect_kind=2)
+    sz, ky, lb = synth.random_db(seed=3, htsize=HT, n_keys=200000, n_targets=40, k=k)
+    off = np.concatenate([[0], np.cumsum(sz.astype(np.int64))])
+    stored = np.concatenate([ky[off[r]:off[r + 1]].astype(np.uint64) * np.uint64(HT) + np.uint64(r) for r in range(0, HT, 997)])
+    kcodes = np.zeros((stored.size, k), dtype=np.uint8)
+    for j in range(k):
+        kcodes[:, j] = ((stored >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)).astype(np.uint8)
+    rp, con = synth.pack_uniform(kcodes)
+    info, want = _check(gpu, oracle, k, sz, ky, lb, rp, con, 40, expect_kind=1)
+    assert (want[:, 2] > 0).all()
+
+
+def test_file_loader_builds_the_records_from_sz_ky_lb(gpu, oracle, tmp_path):
+    """mc_load_db: the files streamed in chunks, twice, through the same build"""
+    k = 27
+    genomes, sz, ky, lb = small_db(k=k, n_targets=8, glen=6000)
+    nzb = np.flatnonzero(sz)
+    canon = np.repeat(nzb, sz[nzb]).astype(np.uint64) + ky.astype(np.uint64) * np.uint64(HT)
+    base = str(tmp_path / "db")
+    oracle.db_write(base, HT, 4, canon, lb)
+    names, seqs = mixed_fasta(genomes, k, n=2000)
+    _, rp, con = pack_with_oracle(oracle, synth.fasta_text(names, seqs, width=70), k)
+    want_rows, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).query_rows(k, rp, con, 15)
+    with gpu(k=k, numBatches=1, numTargets=8, device=0, htsize=HT, maxhits=15) as db:
+        assert db.read(base) is True
+        info = db.db_info()
+        got, rows = db.classify(rp, con, extended=True)
+    assert info["index_kind"] == 2 and info["n_keys"] == ky.size
+    assert np.array_equal(rows, want_rows) and np.array_equal(got, oracle.result_rows(want_rows))

@@ -701,6 +701,11 @@ def test_fast_g_format_matches_printf(tmp_path):
     ("0,0,0,0,0", {"MC_GROUP_MODE": "shards", "MC_GROUP_PARTS": "2"}, "shards by minimizer line range: 2 parts x 2 groups"),
     # the minimizer lines "do not fit" anywhere (MC_MZ_ALLOC_LIMIT): one member falls back to the bucket-line table, two
     # members first cut the table into parts, then fall back to the reference's bucket ranges
+    # the super-k-mer index (MC_INDEX=skm) behind the same group interface: replicas, and parts by minimizer whose members
+    # take the first member's line count
+    ("0,0,0", {"MC_INDEX": "skm"}, "replicas"),
+    ("0,0", {"MC_GROUP_MODE": "shards", "MC_INDEX": "skm"}, "shards by minimizer line range"),
+    ("0,0,0", {"MC_GROUP_MODE": "shards", "MC_INDEX": "auto"}, "shards by minimizer line range"),
     ("0", {"MC_MZ_ALLOC_LIMIT": "65536"}, "replicas"),
     ("0,0", {"MC_MZ_ALLOC_LIMIT": "65536"}, "shards by bucket range"),
 ])
@@ -751,6 +756,8 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
                           capture_output=True, text=True, timeout=900, env=e)
     assert many.returncode == 0, many.stderr
     assert ("Devices: %d (%s" % (len(members.split(",")), expect)) in many.stderr, many.stderr
+    if env.get("MC_INDEX") in ("skm", "auto"):
+        assert "super-k-mer index" in many.stderr, many.stderr
     if "MC_MZ_ALLOC_LIMIT" in env:
         assert "falling back to the bucket-line table" in many.stderr and "[fallback: the minimizer index did not fit]" in many.stderr, many.stderr
     if "replicas" not in expect and "parts x" not in expect:
