@@ -173,7 +173,8 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     if (want == 0)
         return fail(MC_EINVAL, "minimizer index: " + std::to_string(n_keys_total) + " k-mers at " + std::to_string(per_line) +
                                " per line over " + std::to_string(n_parts) + " part(s) need more than 2^32 lines per part");
-    const bool both = use_both(c);
+    if (!c->group_loading) { c->auto_decision = 0; c->sk_d_hint = 0; }
+    const bool both = use_both(c) && (n_parts == 1 || c->group_loading);
     if (both) {          // the super-k-mer build's counters first (it resets the context), the minimizer index's next to them
         const int rc = sk_begin(c, n_keys_total, part, n_parts);
         if (rc != MC_OK) return rc;
@@ -347,7 +348,8 @@ int index_next_pass(mc_ctx *c)
         const double fano = mean > 0.0 ? ((double)mom[1] / nf - mean * mean) / mean : 0.0;
         double need = 2.5;
         if (const char *e = getenv("MC_AUTO_CLUMP")) { const double v = atof(e); if (v > 0.0) need = v; }
-        const bool records = fano >= need;
+        const bool records = c->auto_decision ? c->auto_decision == 1 : fano >= need;
+        c->auto_decision = records ? 1 : 2;
         if (getenv("MC_SKM_VERBOSE"))
             fprintf(stderr, "libmcclark: MC_INDEX=auto: variance / mean of the k-mers per fine line %.2f -> %s\n", fano, records ? "super-k-mer records" : "minimizer lines");
         B.both = false;
@@ -488,6 +490,7 @@ int sk_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_parts)
 {
     free_db(c);
     index_abort(c);
+    if (!c->group_loading) c->sk_d_hint = 0;
     // fine lines: about one per two k-mers of this part (the final lines are 1 .. 12 of them each)
     double per_fine = 2.0;
     if (const char *e = getenv("MC_SKM_FINE")) { const double v = atof(e); if (v >= 0.25 && v <= 64.0) per_fine = v; }
@@ -1182,6 +1185,7 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
     auto abort_all = [&]() { const std::string keep = g_err; for (uint32_t i = 0; i < n; i++) { (void)hipSetDevice(ctxs[i]->device); free_db(ctxs[i]); index_abort(ctxs[i]); } g_err = keep; };
     for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
         rc = set_dev(ctxs[i]);
+        ctxs[i]->group_loading = true; ctxs[i]->auto_decision = 0;
         if (rc == MC_OK) rc = index_begin(ctxs[i], F.n_keys_kept, (part0 + i) % n_parts, n_parts);
     }
     if (rc != MC_OK) { abort_all(); return rc; }
@@ -1310,12 +1314,14 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
             // (super-k-mer records: the first member's merge factor is everybody's -- the parts of one table must agree
             // on the line count, and replicas may as well)
             if (pass == 1) ctxs[i]->sk_d_hint = i ? ctxs[0]->sk_d : 0;
+            if (pass == 0 && i) ctxs[i]->auto_decision = ctxs[0]->auto_decision;     // MC_INDEX=auto: one choice for the group
             if (rc == MC_OK) rc = pass == 0 ? index_next_pass(ctxs[i]) : index_end(ctxs[i]);
         }
     }
     const std::string keep = g_err;
     cleanup();
     g_err = keep;
+    for (uint32_t i = 0; i < n; i++) { ctxs[i]->group_loading = false; ctxs[i]->auto_decision = 0; ctxs[i]->sk_d_hint = 0; }
     if (rc != MC_OK) abort_all();
     return rc;
 }
@@ -1391,7 +1397,7 @@ int mc_open(mc_ctx **out, int device, uint32_t k, uint64_t htsize, uint32_t num_
     c->device = device; c->k = k; c->htsize = htsize; c->num_targets = num_targets; c->maxhits = maxhits;
     c->div = mc::make_div(htsize);
     c->wide = wide;
-    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : strcmp(e, "skm") == 0 ? 2 : strcmp(e, "auto") == 0 ? 3 : 1;
+    if (const char *e = getenv("MC_INDEX")) c->index_mode = strcmp(e, "lines") == 0 ? 0 : strcmp(e, "skm") == 0 ? 2 : strcmp(e, "auto") == 0 ? 3 : 1;      // default: auto
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);

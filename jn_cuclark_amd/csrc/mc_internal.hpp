@@ -116,8 +116,12 @@ struct mc_ctx {
     // locality-aware index (mc_minimizer.hpp): the default for k >= 16; MC_INDEX=lines
     // selects the direct bucket-line table instead (also the fallback when the minimizer
     // lines do not fit in HBM)
-    int index_mode = 1;                // 0 = bucket lines, 1 = minimizer lines, 2 = super-k-mer records (where k allows, else 1),
-                                       // 3 = minimizer lines or super-k-mer records, whichever suits the table (where k allows, else 1)
+    int index_mode = 3;                // 0 = bucket lines (MC_INDEX=lines), 1 = minimizer lines (=minimizer), 2 = super-k-mer records
+                                       // (=skm; where k allows, else 1), 3 = minimizer lines or super-k-mer records, whichever suits
+                                       // the table (=auto, the default; where k allows and the table is built whole or by a group
+                                       // loader -- parts that are built one by one cannot agree on a choice and get minimizer lines)
+    int auto_decision = 0;             // a group loader's first member decided: 1 = records, 2 = lines (0 = decide here)
+    bool group_loading = false;        // the build is driven by load_streamed (all members of a group in step)
     uint32_t sk_d = 0;                 // merge factor the super-k-mer index was built with ...
     uint32_t sk_d_hint = 0;            // ... and the one a group loader prescribes (all members: one layout; 0 = choose here)
     uint8_t *d_sk_lines = nullptr, *d_sk_extra = nullptr;      // super-k-mer index: lines of 8 slots, extra lines (chains)

@@ -225,7 +225,7 @@ def test_auto_picks_records_for_genomes_and_lines_for_isolated_kmers(gpu, oracle
         kcodes[:, j] = ((stored >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)).astype(np.uint8)
     rp, con = synth.pack_uniform(kcodes)
     info, want = _check(gpu, oracle, k, sz, ky, lb, rp, con, 40, expect_kind=1)
-    assert (want[:, 2] > 0).all()
+    assert (want[:, 2] > 0).mean() > 0.3        # (a random quotient is the canonical form of its k-mer about half the time)
 
 
 def test_file_loader_builds_the_records_from_sz_ky_lb(gpu, oracle, tmp_path):
@@ -235,12 +235,12 @@ def test_file_loader_builds_the_records_from_sz_ky_lb(gpu, oracle, tmp_path):
     nzb = np.flatnonzero(sz)
     canon = np.repeat(nzb, sz[nzb]).astype(np.uint64) + ky.astype(np.uint64) * np.uint64(HT)
     base = str(tmp_path / "db")
-    oracle.db_write(base, HT, 4, canon, lb)
+    oracle.db_write(base, HT, 8, canon, lb)          # (k = 27 over 1000003 buckets: the quotients need more than 32 bits)
     names, seqs = mixed_fasta(genomes, k, n=2000)
     _, rp, con = pack_with_oracle(oracle, synth.fasta_text(names, seqs, width=70), k)
     want_rows, _ = oracle.OracleDB.from_arrays(HT, sz, ky, lb).query_rows(k, rp, con, 15)
     with gpu(k=k, numBatches=1, numTargets=8, device=0, htsize=HT, maxhits=15) as db:
-        assert db.read(base) is True
+        assert db.read(base, key_bytes=8) is True
         info = db.db_info()
         got, rows = db.classify(rp, con, extended=True)
     assert info["index_kind"] == 2 and info["n_keys"] == ky.size
