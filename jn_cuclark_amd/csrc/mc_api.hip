@@ -121,10 +121,17 @@ bool use_sk(const mc_ctx *c) { return c->index_mode == 2 && mc::sk::sk_supported
 
 bool use_both(const mc_ctx *c) { return c->index_mode == 3 && mc::sk::sk_supported(c->k); }
 
-// the lines of the minimizer index (+ the room reserved behind them), filled with "empty"
-int mz_alloc_lines(mc_ctx *c)
+// The lines of the minimizer index and, right behind them in the SAME allocation, exactly the extra lines the first build
+// pass counted.  Round 3 allocated the lines at mc_index_begin with a guessed share for the extra lines behind them
+// (12-90 %: 28 GB behind the headline table, which used 1.7); round 4 allocates between the passes, when the number is known.
+// Measured on the way (one box, 10 M reads per launch): extra lines in an allocation of their own -- a late hipMalloc or a
+// hipMemCreate / hipMemMap range -- cost the genome-shaped table 9.5 ms instead of 7.1 (it is being ANOTHER address range
+// that costs, not small pages); lines AND extra lines mapped into one reserved range (hipMemAddressReserve + two hipMemMap)
+// run 7.1 there but the headline table 6.18 instead of 6.02 ms.  One hipMalloc of the exact size has neither cost.
+int mz_alloc_lines(mc_ctx *c, uint64_t n_extra)
 {
     const size_t lbytes = (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
+    const size_t ebytes = (size_t)(n_extra ? n_extra : 1) * mc::mz::MZ_LINE;
     // MC_MZ_ALLOC_LIMIT (bytes): a cap on the lines of one context -- a card shared with other tenants, and how the tests
     // reach the "does not fit" paths (the fallback to the bucket-line table, a group that cuts the table into more parts)
     if (const char *e = getenv("MC_MZ_ALLOC_LIMIT")) {
@@ -132,18 +139,15 @@ int mz_alloc_lines(mc_ctx *c)
         if (lim && (uint64_t)lbytes > lim)
             return fail(MC_ENOMEM, "minimizer lines of " + std::to_string(lbytes) + " bytes exceed MC_MZ_ALLOC_LIMIT");
     }
-    // room for the extra lines behind the primary lines, in the same allocation (mc_internal.hpp): the share the
-    // loader's budget assumes for this fill (index_bytes), which a genome-shaped table stays below
-    uint64_t reserve = c->build.mz_reserve;
-    if (hipMalloc(&c->d_mz_lines, lbytes + (size_t)reserve * mc::mz::MZ_LINE) != hipSuccess) {
+    if (hipMalloc(&c->d_mz_lines, lbytes + ebytes) != hipSuccess) {
         (void)hipGetLastError();
-        reserve = 0;                                            // a tight card: the lines alone, the extra lines where they fit
         c->d_mz_lines = nullptr;
-        if (hipMalloc(&c->d_mz_lines, lbytes) != hipSuccess) { (void)hipGetLastError(); c->d_mz_lines = nullptr; }
+        return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes + ebytes) + " bytes of minimizer lines (" +
+                               std::to_string(n_extra) + " extra lines among them); a denser MC_MZ_FILL needs less");
     }
-    c->mz_extra_reserved = reserve;
-    if (!c->d_mz_lines) return fail(MC_ENOMEM, "not enough HBM for " + std::to_string(lbytes) + " bytes of minimizer lines");
-    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes, c->streams[0]));
+    c->d_mz_extra = c->d_mz_lines + lbytes;
+    c->mz_extra_reserved = n_extra; c->mz_extra_own_alloc = false;
+    HIPCHK(hipMemsetAsync(c->d_mz_lines, 0xFF, lbytes + ebytes, c->streams[0]));
     return MC_OK;
 }
 
@@ -186,11 +190,16 @@ int index_begin(mc_ctx *c, uint64_t n_keys_total, uint32_t part, uint32_t n_part
     c->info = mc_db_info{};
     c->info.part = part; c->info.n_parts = n_parts;
     c->build.mz_per_line = per_line;
-    c->build.mz_reserve = getenv("MC_MZ_NO_RESERVE") ? 0 : (uint64_t)((double)c->mz_n_local * mcint::extra_share(per_line)) + 64;
     hipStream_t st = c->streams[0];
     uint32_t **cnt = both ? &c->build.d_count_mz : &c->build.d_count;
-    // (MC_INDEX=auto: the lines are allocated between the passes, once it is known which index they are for)
-    int rc = both ? (int)MC_OK : mz_alloc_lines(c);
+    // (the lines are allocated between the passes: then it is known how many extra lines go behind them -- and, with
+    // MC_INDEX=auto, which index they are for)
+    int rc = MC_OK;
+    if (const char *e = getenv("MC_MZ_ALLOC_LIMIT")) {          // (refused here already: the callers' fallbacks key on mc_index_begin)
+        const uint64_t lim = strtoull(e, nullptr, 10);
+        if (lim && (uint64_t)c->mz_n_local * mc::mz::MZ_LINE > lim && !both)
+            rc = fail(MC_ENOMEM, "minimizer lines of " + std::to_string((uint64_t)c->mz_n_local * mc::mz::MZ_LINE) + " bytes exceed MC_MZ_ALLOC_LIMIT");
+    }
     if (rc == MC_OK && (hipMalloc(cnt, (size_t)(c->mz_n_local ? c->mz_n_local : 1) * 4) != hipSuccess ||
                         (!c->build.d_failed && hipMalloc(&c->build.d_failed, 4) != hipSuccess))) {
         (void)hipGetLastError();
@@ -360,8 +369,6 @@ int index_next_pass(mc_ctx *c)
             (void)hipFree(B.d_count); (void)hipFree(B.d_cursor); (void)hipFree(B.d_off32); (void)hipFree(B.d_blk_base);
             B.d_count = B.d_count_mz; B.d_count_mz = nullptr; B.d_cursor = nullptr; B.d_off32 = nullptr; B.d_blk_base = nullptr;
             B.sk = false;
-            const int rc = mz_alloc_lines(c);
-            if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; return rc; }
         }
     }
     if (c->build.sk) return sk_next_pass(c);
@@ -390,18 +397,10 @@ int index_next_pass(mc_ctx *c)
     if (acc >= 0xFFFFFFFFull) { free_db(c); index_abort(c); return fail(MC_EINVAL, "minimizer index: more than 2^32 extra lines"); }
     c->build.n_extra = acc; c->build.n_spilled = tot[0]; c->build.n_over = tot[1]; c->build.longest = (uint32_t)tot[2];
     c->build.n_crowded = tot[3];
-    const size_t ebytes = (size_t)(acc ? acc : 1) * mc::mz::MZ_LINE;
-    if (acc <= c->mz_extra_reserved && c->mz_extra_reserved) {
-        c->d_mz_extra = c->d_mz_lines + (size_t)(c->mz_n_local ? c->mz_n_local : 1) * mc::mz::MZ_LINE;
-        c->mz_extra_own_alloc = false;
-    } else if (hipMalloc(&c->d_mz_extra, ebytes) == hipSuccess) {
-        c->mz_extra_own_alloc = true;
-    } else {
-        (void)hipGetLastError();
-        free_db(c); index_abort(c);
-        return fail(MC_ENOMEM, "minimizer index: not enough HBM for the extra lines");
+    {
+        const int rc = mz_alloc_lines(c, acc);
+        if (rc != MC_OK) { const std::string keep = g_err; free_db(c); index_abort(c); g_err = keep; return rc; }
     }
-    HIPCHK(hipMemsetAsync(c->d_mz_extra, 0xFF, ebytes, st));
     HIPCHK(hipMemcpyAsync(d_boff, boff.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mc::mz::mz_header_kernel, dim3(nblk), dim3(mc::RL_THREADS), 0, st, c->build.d_count, n, d_boff, c->d_mz_lines, c->k);
     HIPCHK(hipGetLastError());
@@ -451,7 +450,7 @@ int index_end(mc_ctx *c)
     I.n_overflow_keys = c->build.n_spilled;
     I.line_bytes = mc::mz::MZ_LINE;
     I.line_capacity = mc::mz::MZ_CAP;
-    I.device_bytes = ((uint64_t)c->mz_n_local + c->mz_extra_reserved + (c->mz_extra_own_alloc ? c->build.n_extra : 0)) * mc::mz::MZ_LINE;
+    I.device_bytes = ((uint64_t)c->mz_n_local + c->mz_extra_reserved) * mc::mz::MZ_LINE;
     I.index_kind = MC_INDEX_MINIMIZER;
     I.n_lines = (uint64_t)c->mz_n_local * c->mz_n_parts;                 // part p = lines [p * n, (p + 1) * n) of the table's
     I.line_begin = (uint64_t)c->mz_n_local * c->mz_part; I.line_end = I.line_begin + c->mz_n_local;
@@ -1118,11 +1117,15 @@ uint64_t lines_per_part(uint64_t n_keys_total, uint32_t n_parts, double fill)
     return per >= MZ_MAX_LINES ? 0 : per;
 }
 
-// extra lines per primary line the budget assumes at `fill` k-mers per line (measured on a genome-shaped table, which
-// overflows more than a random one)
+// Extra lines per primary line the budget assumes at `fill` k-mers per line.  Round 3 took the shares of the genome-shaped
+// table (12 % at 3-4 per line ... 90 % at 12) and ALLOCATED them: 28 GB behind the headline table, which used 1.7.  Round 4:
+// the extra lines are backed exactly (mc_ctx::Vmm) and tables whose k-mers clump around their minimizers go to the
+// super-k-mer index (MC_INDEX=auto), so the estimate is that of k-mers that spread like a Poisson process over 12-slot lines
+// (P(more than 12 | fill) = 0.001 / 0.09 / 0.9 / 6.4 / 21 / 42 % at 3.5 / 5 / 7 / 8 / 10 / 12 per line), with a margin; a table
+// that needs more gets it while the card has it (MC_ENOMEM at mc_index_next_pass otherwise: MC_MZ_FILL).
 double extra_share(double fill)
 {
-    return fill <= 4.0 ? 0.12 : fill <= 5.0 ? 0.17 : fill <= 6.0 ? 0.22 : fill <= 7.0 ? 0.32 : fill <= 8.0 ? 0.45 : fill <= 10.0 ? 0.65 : 0.9;
+    return fill <= 4.0 ? 0.02 : fill <= 5.0 ? 0.03 : fill <= 6.0 ? 0.05 : fill <= 7.0 ? 0.08 : fill <= 8.0 ? 0.14 : fill <= 10.0 ? 0.40 : 0.8;
 }
 
 // HBM one context needs for its share of a minimizer index at `fill` k-mers per line: lines, extra lines (the

@@ -79,7 +79,7 @@ struct IndexBuild {
     // minimizers (the counts of the fine lines) and goes on with one of them
     bool both = false;
     uint32_t *d_count_mz = nullptr;
-    uint64_t mz_reserve = 0; double mz_per_line = 0.0;
+    double mz_per_line = 0.0;
     uint32_t sk_n_fine = 0;
     uint32_t *d_cursor = nullptr, *d_off32 = nullptr;
     uint64_t *d_blk_base = nullptr;
@@ -131,8 +131,9 @@ struct mc_ctx {
     // mc_index_begin (the loader's estimate of their share) suffices: an allocation of its own, made after the first
     // build pass from a heap that the build's temporaries have cut up, ends up on small pages, and a fetch from it costs
     // several times a fetch from the primary lines (62-200 ns against 24 ns per line)
-    uint64_t mz_extra_reserved = 0;    // extra lines reserved behind the primary lines
-    bool mz_extra_own_alloc = false;   // d_mz_extra is an allocation of its own (the reserve did not suffice)
+    uint64_t mz_extra_reserved = 0;    // extra lines behind the primary lines, in the same allocation (round 4: exactly the
+                                       // number the first build pass counted; the lines are allocated between the passes)
+    bool mz_extra_own_alloc = false;   // (no longer set: the extra lines never get an allocation of their own)
     uint32_t mz_n_local = 0;           // primary lines held here (every part of a table has the same number)
     uint32_t mz_part = 0, mz_n_parts = 1, mz_m = 0;
     double fill_hint = 0.0;            // k-mers per line chosen by a group loader for all its members (0 = choose here)
