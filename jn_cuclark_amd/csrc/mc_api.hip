@@ -11,6 +11,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -997,15 +998,39 @@ int DbFileStream::open(const char *base_path, int kb, uint32_t smp, uint64_t ht,
     // bucket sizes of the whole table (the sampling counter runs over all non-empty
     // buckets, reference CuClarkDB.cu:503-513)
     sz.resize(htsize);
-    if (!pread_all(fs, sz.data(), htsize, 0)) return fail(MC_EIO, base + ".sz is shorter than htsize");
+    // the 1.6 GB of bucket sizes of a full table: read and summed in slices by several threads (one thread: 0.5 s for the
+    // read, 1.5 s for the sums -- a quarter of what loading the table takes once its files are read only once)
+    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>(8, htsize >> 24));
+    std::vector<uint64_t> below(nt, 0), inside(nt, 0);
+    std::atomic<bool> bad{false};
     const bool all = sampling <= 1;
-    if (!all) fsz = sz;
-    uint64_t nonzero = 0;
+    auto slice = [&](int t) {
+        const uint64_t i0 = htsize * (uint64_t)t / nt, i1 = htsize * (uint64_t)(t + 1) / nt;
+        if (!pread_all(fs, sz.data() + i0, i1 - i0, i0)) { bad = true; return; }
+        if (!all) return;
+        uint64_t lo = 0, in = 0;
+        for (uint64_t i = i0; i < i1; i++) { const uint64_t v = sz[i]; if (i < sb) lo += v; else if (i < se) in += v; }
+        below[t] = lo; inside[t] = in;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(slice, t);
+        slice(0);
+        for (auto &t : th) t.join();
+    }
+    if (bad) return fail(MC_EIO, base + ".sz is shorter than htsize");
     file_k0 = 0; n_keys_kept = 0;
+    if (all) {
+        for (int t = 0; t < nt; t++) { file_k0 += below[t]; n_keys_kept += inside[t]; }
+        return MC_OK;
+    }
+    // -s sampling: the counter runs over all non-empty buckets in order (reference CuClarkDB.cu:503-513)
+    fsz = sz;
+    uint64_t nonzero = 0;
     for (uint64_t i = 0; i < htsize; i++) {
         if (sz[i] == 0) continue;
         nonzero++;
-        const bool kp = all || (nonzero % sampling) == 0;
+        const bool kp = (nonzero % sampling) == 0;
         if (i < sb) file_k0 += sz[i];
         if (!kp) sz[i] = 0;
         else if (i >= sb && i < se) n_keys_kept += sz[i];
@@ -1053,14 +1078,27 @@ void DbFileStream::plan()
     const uint64_t CH = 1ull << 24;   // buckets per chunk
     const std::vector<uint8_t> &file_sz = fsz.empty() ? sz : fsz;
     chunks.clear(); max_nfile = 0; max_nb = 0;
+    for (uint64_t b0 = sb; b0 < se; b0 += CH) chunks.push_back(Chunk{b0, std::min(se, b0 + CH), 0, 0});
+    // the k-mers of every chunk: summed by several threads, chunk by chunk
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t j; (j = next.fetch_add(1)) < chunks.size();) {
+            uint64_t nfile = 0;
+            for (uint64_t i = chunks[j].b0; i < chunks[j].b1; i++) nfile += file_sz[i];
+            chunks[j].nfile = nfile;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        const int nt = (int)std::min<size_t>(8, std::max<size_t>(1, chunks.size()));
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
     uint64_t fpos = file_k0;
-    for (uint64_t b0 = sb; b0 < se; b0 += CH) {
-        const uint64_t b1 = std::min(se, b0 + CH);
-        uint64_t nfile = 0;
-        for (uint64_t i = b0; i < b1; i++) nfile += file_sz[i];
-        chunks.push_back(Chunk{b0, b1, fpos, nfile});
-        max_nfile = std::max(max_nfile, nfile); max_nb = std::max(max_nb, b1 - b0);
-        fpos += nfile;
+    for (auto &C : chunks) {
+        C.fpos = fpos; fpos += C.nfile;
+        max_nfile = std::max(max_nfile, C.nfile); max_nb = std::max(max_nb, C.b1 - C.b0);
     }
 }
 
@@ -1169,19 +1207,39 @@ bool minimizer_index_possible(const mc_ctx *c, uint64_t n_keys_total) { return c
 int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_parts, uint32_t part0, double fill)
 {
     int rc = MC_OK;
+    const bool loud = getenv("MC_LOAD_VERBOSE") != nullptr;
+    auto now_s = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t_start = now_s();
+    auto lap = [&](const char *what) { if (loud) fprintf(stderr, "libmcclark: %6.2f s  %s\n", now_s() - t_start, what); };
+    // ONE pass over the files when the card has the room (round 4): the chunks of the first build pass stay in HBM -- one
+    // copy per device, 6 bytes per k-mer + 1 per bucket: 40 GB for the headline table -- and the second pass is fed from
+    // there instead of reading and uploading the 41 GB of files again (8.3-9.2 s for the two passes in round 3).  The
+    // room comes out of the index's budget: taken only if the fill stays within one k-mer per line of what it would be.
+    const uint64_t resident_bytes = (F.se - F.sb) + F.n_keys_kept * (uint64_t)(F.key_bytes + 2) + (4ull << 20);
+    bool one_pass = !getenv("MC_LOAD_TWO_PASSES");
+    uint64_t free_min = ~0ull;
+    uint32_t sharing_max = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        size_t fr = 0, tot = 0;
+        if (set_dev(ctxs[i]) != MC_OK || hipMemGetInfo(&fr, &tot) != hipSuccess) continue;
+        uint32_t sharing = 0;
+        for (uint32_t o = 0; o < n; o++) sharing += ctxs[o]->device == ctxs[i]->device ? 1u : 0u;
+        free_min = std::min<uint64_t>(free_min, fr / sharing);
+        sharing_max = std::max(sharing_max, sharing);
+    }
+    if (const char *e = getenv("MC_GROUP_HBM_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) free_min = std::min(free_min, v); }
+    {
+        const uint64_t take = resident_bytes / sharing_max + (1ull << 30);
+        const double f0 = fill > 0.0 ? fill : choose_fill(F.n_keys_kept, n_parts, free_min);
+        const double f1 = fill > 0.0 ? fill : (free_min > take ? choose_fill(F.n_keys_kept, n_parts, free_min - take) : 99.0);
+        one_pass = one_pass && free_min > take && f1 <= std::max(4.0, f0 + 1.0) &&
+                   index_bytes(F.n_keys_kept, n_parts, f1) + MZ_RESERVE_BYTES <= free_min - take;
+        if (one_pass) free_min -= take;
+    }
     if (fill > 0.0) {
         for (uint32_t i = 0; i < n; i++) ctxs[i]->fill_hint = fill;
     } else if (!getenv("MC_MZ_FILL")) {
         // one fill for all members: what the member with the least free HBM can afford
-        uint64_t free_min = ~0ull;
-        for (uint32_t i = 0; i < n; i++) {
-            size_t fr = 0, tot = 0;
-            if (set_dev(ctxs[i]) != MC_OK || hipMemGetInfo(&fr, &tot) != hipSuccess) continue;
-            uint32_t sharing = 0;
-            for (uint32_t o = 0; o < n; o++) sharing += ctxs[o]->device == ctxs[i]->device ? 1u : 0u;
-            free_min = std::min<uint64_t>(free_min, fr / sharing);
-        }
-        if (const char *e = getenv("MC_GROUP_HBM_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) free_min = std::min(free_min, v); }
         const double f = choose_fill(F.n_keys_kept, n_parts, free_min);
         for (uint32_t i = 0; i < n; i++) ctxs[i]->fill_hint = f;
     }
@@ -1198,7 +1256,8 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
     const size_t cap_k = (size_t)std::max<uint64_t>(F.max_nfile, 1), cap_b = (size_t)std::max<uint64_t>(F.max_nb, 1);
     // per distinct device: copy stream, two staging sets, "copied" events; per member: "built" events
     struct Dev { int device; hipStream_t cs = nullptr; uint8_t *d_sz[2] = {nullptr, nullptr}; char *d_keys[2] = {nullptr, nullptr};
-                 uint16_t *d_labels[2] = {nullptr, nullptr}; hipEvent_t copied[2] = {nullptr, nullptr}; };
+                 uint16_t *d_labels[2] = {nullptr, nullptr}; hipEvent_t copied[2] = {nullptr, nullptr};
+                 uint8_t *r_sz = nullptr; char *r_keys = nullptr; uint16_t *r_labels = nullptr; };      // the whole table, kept for the second pass
     std::vector<Dev> devs;
     std::vector<int> dev_of(n);
     std::vector<hipEvent_t> built((size_t)n * 2, nullptr);
@@ -1218,6 +1277,10 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
                 if (D.copied[s2]) (void)hipEventDestroy(D.copied[s2]);
             }
             if (D.cs) (void)hipStreamDestroy(D.cs);
+            if (D.r_sz) (void)hipFree(D.r_sz);
+            if (D.r_keys) (void)hipFree(D.r_keys);
+            if (D.r_labels) (void)hipFree(D.r_labels);
+            D.r_sz = nullptr; D.r_keys = nullptr; D.r_labels = nullptr;
         }
         for (uint32_t i = 0; i < n; i++)
             for (int s2 = 0; s2 < 2; s2++)
@@ -1242,6 +1305,12 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
                 }
                 HIPCHK(hipEventCreateWithFlags(&D.copied[s2], hipEventDisableTiming));
             }
+            if (one_pass && (hipMalloc(&D.r_sz, (size_t)(F.se - F.sb) + 16) != hipSuccess ||
+                             hipMalloc(&D.r_keys, (size_t)std::max<uint64_t>(F.n_keys_kept, 1) * kb) != hipSuccess ||
+                             hipMalloc(&D.r_labels, (size_t)std::max<uint64_t>(F.n_keys_kept, 1) * 2) != hipSuccess)) {
+                (void)hipGetLastError();
+                one_pass = false;                       // (no room after all: two passes; what was allocated is released by cleanup)
+            }
         }
         for (uint32_t i = 0; i < n; i++) {
             HIPCHK(hipSetDevice(ctxs[i]->device));
@@ -1251,10 +1320,42 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
         return MC_OK;
     };
     rc = setup();
-    int n_threads = 8;
+    int n_threads = 12;
     if (const char *e = getenv("MC_LOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_threads = v; }
 
+    std::vector<uint64_t> kept_off(F.chunks.size() + 1, 0);      // k-mers kept before chunk i (one pass: where it sits in the resident arrays)
+    lap("counters, chunk plan, pinned and staging buffers allocated");
+    if (loud) fprintf(stderr, "libmcclark: loading %.2fe9 k-mers for %u member(s): %s over the files (%d reader threads)\n", (double)F.n_keys_kept / 1e9, n,
+                      one_pass ? "ONE pass" : "two passes", n_threads);
     for (int pass = 0; pass < 2 && rc == MC_OK; pass++) {
+        if (pass == 1) lap("first pass over the files done, lines allocated");
+        if (pass == 1 && one_pass) {
+            // the second pass from the chunks that stayed in HBM
+            for (size_t i = 0; i < F.chunks.size() && rc == MC_OK; i++) {
+                const DbFileStream::Chunk &C = F.chunks[i];
+                for (uint32_t m = 0; m < n && rc == MC_OK; m++) {
+                    Dev &D = devs[dev_of[m]];
+                    rc = set_dev(ctxs[m]);
+                    if (rc == MC_OK)
+                        rc = index_add_device(ctxs[m], D.r_sz + (C.b0 - F.sb), D.r_keys + kept_off[i] * kb, F.key_bytes, D.r_labels + kept_off[i],
+                                              kept_off[i + 1] - kept_off[i], C.b0, C.b1);
+                }
+            }
+            lap("second pass queued (from HBM)");
+            // the raw arrays have done their work: released before the indexes take their final shape
+            for (auto &D : devs) {
+                if (hipSetDevice(D.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); continue; }
+                (void)hipFree(D.r_sz); (void)hipFree(D.r_keys); (void)hipFree(D.r_labels);
+                D.r_sz = nullptr; D.r_keys = nullptr; D.r_labels = nullptr;
+            }
+            for (uint32_t i = 0; i < n && rc == MC_OK; i++) {
+                rc = set_dev(ctxs[i]);
+                ctxs[i]->sk_d_hint = i ? ctxs[0]->sk_d : 0;
+                if (i == 0) lap("raw arrays released");
+                if (rc == MC_OK) rc = index_end(ctxs[i]);
+            }
+            break;
+        }
         // reader: chunk i into host buffer i % 2
         std::mutex mu;
         std::condition_variable cv;
@@ -1280,6 +1381,7 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
             if (rc != MC_OK) break;
             const DbFileStream::Chunk &C = F.chunks[i];
             const uint64_t k_n = nk[s2];
+            if (pass == 0) kept_off[i + 1] = kept_off[i] + k_n;
             auto enqueue = [&]() -> int {
                 for (size_t d = 0; d < devs.size(); d++) {
                     Dev &D = devs[d];
@@ -1290,6 +1392,13 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
                     if (k_n) {
                         HIPCHK(hipMemcpyAsync(D.d_keys[s2], h_keys(s2), k_n * kb, hipMemcpyHostToDevice, D.cs));
                         HIPCHK(hipMemcpyAsync(D.d_labels[s2], h_labels(s2), k_n * 2, hipMemcpyHostToDevice, D.cs));
+                    }
+                    if (one_pass && pass == 0) {          // and a copy that stays, device to device
+                        HIPCHK(hipMemcpyAsync(D.r_sz + (C.b0 - F.sb), D.d_sz[s2], C.b1 - C.b0, hipMemcpyDeviceToDevice, D.cs));
+                        if (k_n) {
+                            HIPCHK(hipMemcpyAsync(D.r_keys + kept_off[i] * kb, D.d_keys[s2], k_n * kb, hipMemcpyDeviceToDevice, D.cs));
+                            HIPCHK(hipMemcpyAsync(D.r_labels + kept_off[i], D.d_labels[s2], k_n * 2, hipMemcpyDeviceToDevice, D.cs));
+                        }
                     }
                     HIPCHK(hipEventRecord(D.copied[s2], D.cs));
                 }
@@ -1321,9 +1430,11 @@ int load_streamed(mc_ctx *const *ctxs, uint32_t n, DbFileStream &F, uint32_t n_p
             if (rc == MC_OK) rc = pass == 0 ? index_next_pass(ctxs[i]) : index_end(ctxs[i]);
         }
     }
+    lap("index built");
     const std::string keep = g_err;
     cleanup();
     g_err = keep;
+    lap("loader's buffers released");
     for (uint32_t i = 0; i < n; i++) { ctxs[i]->group_loading = false; ctxs[i]->auto_decision = 0; ctxs[i]->sk_d_hint = 0; }
     if (rc != MC_OK) abort_all();
     return rc;
