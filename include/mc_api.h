@@ -237,6 +237,23 @@ int mc_result_rows_device(mc_ctx *ctx, const uint16_t *d_rows, uint64_t n_reads,
 int mc_merge_result_device(mc_ctx *ctx, const uint16_t *const *d_srcs, uint32_t n_srcs, uint64_t n_reads,
                            uint16_t *d_out_rows, uint16_t *d_final_rows, void *stream);
 
+/* ---- FASTQ text batches: record boundaries, 2-bit packing and classification on the device (csrc/mc_ingest.hip) ----
+ * An ADDITION to the reference's interface (like --gpu-build): the reference parses and packs on the host
+ * (getObjectsDataComputeFullGPU, src/CuCLARK_hh.hh:1405-1534 FASTQ records, :1629-1707 packing) and hands packed reads to
+ * readyBatch / queryBatch.  Here the caller copies the BYTES of a batch -- whole 4-line FASTQ records, starting at an '@' --
+ * into a pinned buffer; back come the final rows (as mc_wait leaves them) and, per read, the offset of its header line in
+ * the text and the length of its sequence line (the names stay with the caller's text).
+ * status != 0 (mc_text_wait): the batch was NOT classified -- bit 0 a record this code does not vouch for (a header that
+ * does not start with '@', a name that starts with a blank), bit 1 a line count that is not a multiple of four, bit 2 more
+ * reads / containers than allocated -- and the caller packs it on the host (mc_submit).  MC_F_FINAL only. */
+int mc_text_alloc(mc_ctx *ctx, uint32_t n_buffers, uint64_t max_text_bytes, uint64_t max_reads, uint64_t max_containers);
+int mc_text_buffers(mc_ctx *ctx, uint32_t buffer, uint8_t **text, uint32_t **header_offsets, uint32_t **sequence_lengths,
+                    uint16_t **final_rows);
+/* asynchronous: H2D of the text, the ingest kernels and the query kernel are queued; a buffer may be refilled after mc_text_wait */
+int mc_text_submit(mc_ctx *ctx, uint32_t buffer, uint64_t n_bytes);
+int mc_text_wait(mc_ctx *ctx, uint32_t buffer, uint64_t *n_reads, uint32_t *status);
+int mc_text_free(mc_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,6 +203,27 @@ class CuClarkDB:
             self.numBatches = saved
         return (final, rows) if extended else final
 
+    # -- FASTQ text in, final rows out (mc_text_*: records cut and packed on the device) ----------
+    def classify_text(self, text, max_reads=None, max_containers=None):
+        """`text`: bytes of whole 4-line FASTQ records.  Returns (status, final rows [n, 5], header offsets [n], sequence
+        lengths [n]); status != 0: the batch was handed back unclassified (see include/mc_api.h) and the arrays are empty."""
+        n_bytes = len(text)
+        max_reads = int(max_reads or n_bytes // 8 + 16)
+        max_containers = int(max_containers or n_bytes // 4 + 64)
+        check(self._lib.mc_text_alloc(self._h, 1, max(n_bytes + 1, 16), max_reads, max_containers))
+        try:
+            t, h, ln, f = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            check(self._lib.mc_text_buffers(self._h, 0, C.byref(t), C.byref(h), C.byref(ln), C.byref(f)))
+            _np_view(t.value, np.uint8, n_bytes)[:] = np.frombuffer(text, dtype=np.uint8)
+            check(self._lib.mc_text_submit(self._h, 0, n_bytes))
+            n, st = C.c_uint64(), C.c_uint32()
+            check(self._lib.mc_text_wait(self._h, 0, C.byref(n), C.byref(st)))
+            n = int(n.value)
+            fin = _np_view(f.value, np.uint16, n * MC_FINAL_ROW).reshape(n, MC_FINAL_ROW).copy()
+            return int(st.value), fin, _np_view(h.value, np.uint32, n).copy(), _np_view(ln.value, np.uint32, n).copy()
+        finally:
+            check(self._lib.mc_text_free(self._h))
+
     # -- device-resident entry points (torch tensors on this GPU) --------------------
     def query_device(self, reads_ptr_t, containers_t, final_t=None, rows_t=None, stream=None):
         flags = (MC_F_FINAL if final_t is not None else 0) | (MC_F_ROWS if rows_t is not None else 0)

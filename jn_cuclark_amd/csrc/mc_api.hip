@@ -857,13 +857,13 @@ int norm_shard(mc_ctx *c, uint64_t &sb, uint64_t &se)
 namespace mcint {
 
 int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads,
-                 uint64_t n_con, uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st)
+                 uint64_t n_con, uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st, const uint32_t *n_dev)
 {
     if (n_reads == 0) return MC_OK;
     // reads_ptr holds u32 container offsets: one batch is below 2^32 reads and containers (the kernels count in 32 bits)
     if (n_reads > 0xFFFFFFE0ull || n_con > 0xFFFFFFFFull) return fail(MC_EINVAL, "a batch holds at most 2^32 - 32 reads and 2^32 - 1 containers");
     mc::QueryArgs a{};
-    a.reads_ptr = d_ptr; a.containers = d_con; a.n_reads = n_reads; a.n_containers = n_con ? n_con : 1;
+    a.reads_ptr = d_ptr; a.containers = d_con; a.n_reads = n_reads; a.n_containers = n_con ? n_con : 1; a.n_dev = n_dev;
     a.lines = c->d_lines; a.ovf_keys = c->d_ovf_keys; a.ovf_labels = c->d_ovf_labels;
     a.shard_begin = c->info.shard_begin; a.shard_end = c->info.shard_end;
     a.div = c->div; a.k = c->k; a.maxhits = c->maxhits; a.flags = flags;
@@ -1541,6 +1541,7 @@ int mc_close(mc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     mc_free_batches(c);
+    mcint::text_release(c);
     free_db(c);
     index_abort(c);
     if (c->d_over) (void)hipFree(c->d_over);

@@ -119,6 +119,8 @@ struct QueryArgs {
     const uint16_t *containers;     // [len][containers...] per part (ref :1044-1046)
     uint64_t n_reads;
     uint64_t n_containers;
+    const uint32_t *n_dev;          // not NULL: [0] reads, [1] containers of the batch, counted on the device (mc_ingest.hip);
+                                    // n_reads / n_containers are then upper bounds (the grid is sized from them)
     const uint8_t  *lines;          // bucket lines of this shard
     const void     *ovf_keys;       // u32 (narrow) or u64 (wide) quotients of oversized buckets
     const uint16_t *ovf_labels;
@@ -319,13 +321,14 @@ void query_kernel(const QueryArgs a)
 
     const uint32_t k = a.k;
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2u * k)) - 1ull);
-    const uint64_t n_groups = (a.n_reads + GROUP_READS - 1) / GROUP_READS;
+    const uint64_t a_n_reads = a.n_dev ? (uint64_t)a.n_dev[0] : a.n_reads, a_n_con = a.n_dev ? (uint64_t)a.n_dev[1] : a.n_containers;
+    const uint64_t n_groups = (a_n_reads + GROUP_READS - 1) / GROUP_READS;
     const uint64_t gstride = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
     const uint32_t row_len = 2u * a.maxhits + 2u;
 
     for (uint64_t g = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; g < n_groups; g += gstride) {
         const uint64_t r0 = g * GROUP_READS;
-        const uint32_t nr = (uint32_t)((a.n_reads - r0) < GROUP_READS ? (a.n_reads - r0) : GROUP_READS);
+        const uint32_t nr = (uint32_t)((a_n_reads - r0) < GROUP_READS ? (a_n_reads - r0) : GROUP_READS);
 
         // container offsets of the group's reads: lane i holds reads_ptr[r0 + i]
         uint32_t ptr_v = 0;
@@ -345,12 +348,12 @@ void query_kernel(const QueryArgs a)
         if (staged) {
             for (uint32_t j = lane * 8u; c0a + j < c1; j += 64u * 8u) {
                 const uint64_t gi = (uint64_t)c0a + j;
-                if (gi + 8u <= a.n_containers) {
+                if (gi + 8u <= a_n_con) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(a.containers + gi);
                     *reinterpret_cast<uint4 *>(slice + j) = v;
                 } else {
                     for (uint32_t t = 0; t < 8u; t++)
-                        slice[j + t] = (gi + t < a.n_containers) ? a.containers[gi + t] : (uint16_t)0;
+                        slice[j + t] = (gi + t < a_n_con) ? a.containers[gi + t] : (uint16_t)0;
                 }
             }
             // LDS is in order per wave; only the compiler must not reorder
@@ -369,7 +372,7 @@ void query_kernel(const QueryArgs a)
                 const uint32_t li = i - c0a;
                 return slice[li < (uint32_t)(STAGE_CON + 15) ? li : (uint32_t)(STAGE_CON + 15)];
             } else {
-                const uint64_t ii = i < a.n_containers ? i : a.n_containers - 1;
+                const uint64_t ii = i < a_n_con ? i : a_n_con - 1;
                 return a.containers[ii];
             }
         };
@@ -377,7 +380,7 @@ void query_kernel(const QueryArgs a)
         for (uint32_t ri = rs; ri < re; ri++) {
             const uint32_t beg = lane_bcast(ptr_v, ri);
             uint32_t end = lane_bcast(ptr_v, ri + 1u);
-            if ((uint64_t)end > a.n_containers) end = (uint32_t)a.n_containers;
+            if ((uint64_t)end > a_n_con) end = (uint32_t)a_n_con;
 
             // accumulator: lane j = j-th distinct target of this read
             uint32_t acc_t = 0xFFFFFFFFu, acc_c = 0;

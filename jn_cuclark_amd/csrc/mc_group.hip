@@ -529,7 +529,41 @@ int mc_group_sync(mc_group *g)
 int mc_group_free_batches(mc_group *g)
 {
     if (!g) return fail(MC_EINVAL, "group is NULL");
+    for (mc_ctx *c : g->ctx) (void)mc_text_free(c);
     return free_batches(g);
+}
+
+/* FASTQ text batches (mc_text_*, csrc/mc_ingest.hip) for a group whose members each hold the whole table: buffer b lives on
+ * member b % N (its buffer b / N), so the batches of a file go round the members.  A table that is cut into parts has no
+ * text path (every part would have to cut and pack every batch): MC_ESTATE, the caller packs on the host. */
+int mc_group_text_alloc(mc_group *g, uint32_t n_buffers, uint64_t max_text, uint64_t max_reads, uint64_t max_con)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    if (!g->loaded) return fail(MC_ESTATE, "mc_group_text_alloc before a database was loaded");
+    if (g->info.mode != MC_GROUP_REPLICAS) return fail(MC_ESTATE, "text batches need a group whose members hold the whole table");
+    const uint32_t n = W(g);
+    for (uint32_t m = 0; m < n; m++) {
+        const uint32_t mine = (n_buffers + n - 1 - m) / n;
+        if (!mine) continue;
+        const int rc = mc_text_alloc(g->ctx[m], mine, max_text, max_reads, max_con);
+        if (rc != MC_OK) { for (mc_ctx *c : g->ctx) (void)mc_text_free(c); return rc; }
+    }
+    return MC_OK;
+}
+int mc_group_text_buffers(mc_group *g, uint32_t buffer, uint8_t **text, uint32_t **hdr, uint32_t **len, uint16_t **fin)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    return mc_text_buffers(g->ctx[buffer % W(g)], buffer / W(g), text, hdr, len, fin);
+}
+int mc_group_text_submit(mc_group *g, uint32_t buffer, uint64_t n_bytes)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    return mc_text_submit(g->ctx[buffer % W(g)], buffer / W(g), n_bytes);
+}
+int mc_group_text_wait(mc_group *g, uint32_t buffer, uint64_t *n_reads, uint32_t *status)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    return mc_text_wait(g->ctx[buffer % W(g)], buffer / W(g), n_reads, status);
 }
 
 } // extern "C"

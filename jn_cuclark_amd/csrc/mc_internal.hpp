@@ -89,8 +89,11 @@ struct IndexBuild {
 
 } // namespace mcint
 
+namespace mcint { struct TextState; void text_release(mc_ctx *c); }
+
 struct mc_ctx {
     int device = 0;
+    mcint::TextState *text = nullptr;  // FASTQ text batches (mc_ingest.hip)
     uint32_t k = 0, num_targets = 0, maxhits = 0;
     uint64_t htsize = 0;
     mc::DivU64 div{};
@@ -155,8 +158,9 @@ namespace mcint {
 int set_dev(mc_ctx *c);
 
 // one query launch on `st` (no synchronisation)
+// n_dev != nullptr: the batch's reads ([0]) and containers ([1]) are counted on the device; n_reads / n_con are upper bounds
 int launch_query(mc_ctx *c, const uint32_t *d_ptr, const uint16_t *d_con, uint64_t n_reads, uint64_t n_con,
-                 uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st);
+                 uint32_t flags, uint16_t *d_final, uint16_t *d_rows, hipStream_t st, const uint32_t *n_dev = nullptr);
 // one batch of the batch interface: H2D, kernel, D2H on the context's three queues; `done` behind the D2H.  The
 // device buffers are c->slots[], dealt by submission order.
 int submit_batch(mc_ctx *c, const uint32_t *h_ptr, const uint16_t *h_con, uint16_t *h_final, uint16_t *h_rows,

@@ -442,7 +442,7 @@ void mz_header_kernel(const uint32_t *count, uint64_t n, const uint64_t *blk_ext
 // nothing is sorted in memory.  The result no longer depends on the order the atomics happened to run in.
 static_assert(MZ_CHAIN_CAP <= 64, "one lane per chain entry");
 static_assert((MZ_RUNS & (MZ_RUNS - 1)) == 0, "runs per batch: a power of two (index mask in the match)");
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint32_t m,
                        uint8_t *lines, uint8_t *extra_lines)
 {
@@ -552,7 +552,7 @@ void mz_regroup_kernel(const uint32_t *count, uint32_t n_lines, uint32_t k, uint
 // slots = all ones come last), labels moved along.  A lookup then compares its k-mer with the 7th key and scans only the half of the line that can
 // hold it (mz_match_line): 6 compares instead of 12.  It also makes the first lines independent of the order
 // the placing pass's atomics ran in.  One lane per line, odd-even transposition in registers (build time only).
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void mz_sort_lines_kernel(uint8_t *lines, uint32_t n_lines)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -728,7 +728,7 @@ void mz_query_kernel(const MzArgs A)
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
     // a batch holds fewer than 2^32 reads and containers (reads_ptr is u32; launch_query checks): 32-bit
     // counters, half the scalar registers
-    const uint32_t n_reads = (uint32_t)a.n_reads, n_con = (uint32_t)a.n_containers;
+    const uint32_t n_reads = a.n_dev ? a.n_dev[0] : (uint32_t)a.n_reads, n_con = a.n_dev ? a.n_dev[1] : (uint32_t)a.n_containers;
     const uint32_t n_groups = (n_reads + (GROUP_READS - 1)) / GROUP_READS;
     const uint32_t gstride = gridDim.x * WAVES_PER_BLOCK;
     // wave-uniform switches are tested where they are used, from ONE scalar register (hoisted out of the

@@ -392,7 +392,7 @@ __device__ __forceinline__ uint32_t sk_form_records(SkSlot &e, uint32_t n, uint3
 }
 
 // records per FINE line (0xFFFF: more entries than a wave handles)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void sk_records_kernel(const uint32_t *count0, const uint32_t *off32, const uint64_t *blk_base, const SkSlot *entries,
                        uint32_t n_fine, uint32_t *nrec)
 {
@@ -472,7 +472,7 @@ void sk_extras_kernel(const uint32_t *count0, const uint32_t *nrec, uint64_t n_l
 }
 
 // the lines: one wave per final line that holds anything
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void sk_encode_kernel(const uint32_t *count0, const uint32_t *off32, const uint64_t *blk_base, const SkSlot *entries,
                       const uint32_t *nrec, uint32_t n_lines, uint32_t d, const uint32_t *xoff32, const uint64_t *xblk_base,
                       uint8_t *lines, uint8_t *extra, unsigned int *failed)
@@ -627,7 +627,7 @@ void sk_query_kernel(const SkArgs A)
     constexpr uint32_t W = SK_W;
     const uint64_t kmask = (1ull << (2u * k)) - 1ull;          // k <= 31
     const uint64_t mmask = (1ull << (2u * m)) - 1ull;
-    const uint32_t n_reads = (uint32_t)a.n_reads, n_con = (uint32_t)a.n_containers;
+    const uint32_t n_reads = a.n_dev ? a.n_dev[0] : (uint32_t)a.n_reads, n_con = a.n_dev ? a.n_dev[1] : (uint32_t)a.n_containers;
     const uint32_t n_groups = (n_reads + (GROUP_READS - 1)) / GROUP_READS;
     const uint32_t gstride = gridDim.x * WAVES_PER_BLOCK;
     auto flags_now = [&]() -> uint32_t { uint32_t f = a.flags; asm volatile("" : "+s"(f)); return f; };

@@ -130,6 +130,8 @@ struct Options {
     const char *targets = nullptr, *folder = nullptr, *objects = nullptr, *objects2 = nullptr, *results = nullptr;
     const char *dump = nullptr;      // test hook: write the packed batches here
     bool gpu_build = false;          // --gpu-build / MC_GPU_BUILD=1: build a missing database on the GPU
+    bool gpu_ingest = true;          // large plain FASTQ files: the card cuts and packs the records (mc_text_*); --host-ingest /
+                                     // MC_GPU_INGEST=0: the host does, as for every other input
 };
 
 struct Classifier {
@@ -139,6 +141,7 @@ struct Classifier {
     int key_bytes = 4;
     mc_group *grp = nullptr;
     bool paired = false;
+    bool text_path = false;          // every member of the group holds the whole table: FASTQ batches may go to the card as text
     size_t n_objects = 0;
 
     void open_devices()
@@ -189,6 +192,7 @@ struct Classifier {
         mc_check(rc, "mc_group_load_db");
         mc_group_info gi;
         mc_group_get_info(grp, &gi);
+        text_path = gi.mode == MC_GROUP_REPLICAS;
         if (opt.verbose) {
             mc_ctx *c0 = nullptr;
             mc_db_info info;
@@ -273,6 +277,7 @@ struct Classifier {
         bool indexed = false, submitted = false;
         ReadIndex own2;                 // mates classified straight from their two files: the records of file 2
         const uint8_t *text2 = nullptr;
+        const uint32_t *dev_hdr = nullptr, *dev_len = nullptr;      // records cut on the card (mc_text_*): header offsets, sequence lengths
     };
     // file 2 of a pair, when the mates are not joined into one text first (streamed plan only)
     struct Mates { const uint8_t *b; size_t nb; };
@@ -310,6 +315,7 @@ struct Classifier {
         // sizes guessed from the head of the file (10 % head room); the guess is checked against what the index
         // says (whole-file plan: the buffers are allocated again if it was too small; streamed: see above).
         size_t guess_reads = 0, guess_con = 0, guess_nbuf = 0;
+        bool dev_ingest = false;
         std::thread early_alloc;
         int early_rc = MC_OK;
         std::string early_err;
@@ -325,13 +331,16 @@ struct Classifier {
                 guess_reads = (size_t)((double)nb / per_read / (double)nbatch_g * 1.10) + 64;
                 guess_con = (size_t)((double)guess_reads * con_per_read * (mates ? 2.2 : 1.05)) + 64;      // (a mate of its own per read)
                 guess_nbuf = std::min(nbatch_g, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
-                if (guess_con <= 0xFFFFFFFFull)
+                // (plain FASTQ, streamed, final rows only: the card cuts and packs the records -- its buffers are allocated below,
+                // once the byte ranges are known)
+                dev_ingest = streamed && opt.gpu_ingest && map[0] == '@' && !mates && !opt.ext && !opt.dump && guess_con <= 0xFFFFFFFFull && text_path;
+                if (guess_con <= 0xFFFFFFFFull && !dev_ingest)
                     early_alloc = std::thread([&]() {
                         early_rc = mc_group_alloc_batches(grp, (uint32_t)guess_nbuf, guess_reads, guess_con, opt.ext ? 1 : 0);
                         if (early_rc != MC_OK) early_err = mc_last_error();
                     });
             }
-            if (streamed && !early_alloc.joinable()) { std::fclose(fout); return false; }     // no guess: whole-file plan
+            if (streamed && !early_alloc.joinable() && !dev_ingest) { std::fclose(fout); return false; }     // no guess: whole-file plan
         }
 
         size_t nbatch, nbuf, cap_reads = 0, cap_con = 0;
@@ -368,6 +377,14 @@ struct Classifier {
                     std::fclose(fout);
                     return false;
                 }
+            }
+            if (dev_ingest) {
+                size_t max_text = 16;
+                for (size_t b = 0; b < nbatch; b++) max_text = std::max(max_text, cut[b + 1] - cut[b] + 16);
+                early_alloc = std::thread([&, max_text]() {
+                    early_rc = mc_group_text_alloc(grp, (uint32_t)guess_nbuf, max_text, guess_reads, guess_con);
+                    if (early_rc != MC_OK) early_err = mc_last_error();
+                });
             }
             B.resize(nbatch);
             ts1 = ts2 = now();
@@ -421,12 +438,17 @@ struct Classifier {
         Pool pool((int)std::max<size_t>(1, opt.cpu));
         std::mutex submit_mu, done_mu;
         std::condition_variable done_cv;
-        bool buffers_ready = !streamed, gave_up = false;        // under done_mu
+        bool buffers_ready = !streamed, gave_up = false, dev_gave_up = false;        // under done_mu
         auto index_batch = [&](size_t b) {
             Batch &X = B[b];
             std::string ierr;
             const size_t len = cut[b + 1] - cut[b];
             X.R = &X.own; X.text = map + cut[b]; X.r0 = 0;
+            if (dev_ingest) {          // the card will say where the records are
+                { std::lock_guard<std::mutex> lk(done_mu); X.indexed = true; }
+                done_cv.notify_all();
+                return;
+            }
             if (len && !index_reads(map + cut[b], len, X.own, ierr)) { std::cerr << ierr << std::endl; std::exit(-1); }
             X.n = X.own.size();
             bool mates_ok = true;
@@ -457,7 +479,15 @@ struct Classifier {
                 done_cv.wait(lk, [&]() { return gave_up || (X.indexed && buffers_ready); });
                 stop = gave_up;
             }
-            if (!stop) {
+            if (!stop && dev_ingest) {
+                const uint32_t buf = (uint32_t)(b % nbuf);
+                uint8_t *dst;
+                mc_check(mc_group_text_buffers(grp, buf, &dst, nullptr, nullptr, nullptr), "mc_group_text_buffers");
+                const size_t len = cut[b + 1] - cut[b];
+                std::memcpy(dst, map + cut[b], len);
+                std::lock_guard<std::mutex> lk(submit_mu);
+                mc_check(mc_group_text_submit(grp, buf, len), "mc_group_text_submit");
+            } else if (!stop) {
                 const uint32_t buf = (uint32_t)(b % nbuf);
                 uint32_t *ptr; uint16_t *con;
                 mc_check(mc_group_batch_buffers(grp, buf, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
@@ -477,7 +507,7 @@ struct Classifier {
             for (size_t b = 0; b < nbuf; b++) pool.run([&, b]() { index_batch(b); pack_batch(b); });
             for (size_t b = nbuf; b < nbatch; b++) pool.run([&, b]() { index_batch(b); });
             early_alloc.join();
-            if (early_rc != MC_OK) die(std::string("mc_group_alloc_batches: ") + early_err);
+            if (early_rc != MC_OK) die(std::string(dev_ingest ? "mc_group_text_alloc: " : "mc_group_alloc_batches: ") + early_err);
             { std::lock_guard<std::mutex> lk(done_mu); buffers_ready = true; }
             done_cv.notify_all();
         } else {
@@ -526,6 +556,16 @@ struct Classifier {
             const uint8_t *text = X.text;
             const size_t r0 = X.r0, nr = X.n;
             const size_t i0 = r0 + nr * sl / nfmt, i1 = r0 + nr * (sl + 1) / nfmt;
+            if (X.dev_hdr) {
+                // records cut on the card: name = the bytes behind '@' up to the first blank / newline, length = the sequence line's
+                ReadIndex &W = const_cast<Batch &>(X).own;
+                const size_t avail = (size_t)(map + nb - text);
+                for (size_t i = i0; i < i1; i++) {
+                    size_t e = (size_t)X.dev_hdr[i] + 2;
+                    while (e < avail && !is_sep(text[e])) e++;
+                    W.name_s[i] = (uint64_t)X.dev_hdr[i] + 1; W.name_e[i] = e; W.len[i] = X.dev_len[i];
+                }
+            }
             // worst case: name + ",<gamma>," + assignment + ",<best>,<confidence>\n" (+ ",65535" per target when extended)
             size_t cap = 0;
             for (size_t i = i0; i < i1; i++) cap += std::min<size_t>(RI.name_e[i] - RI.name_s[i], OBJECTNAMEMAX - 1);
@@ -623,9 +663,25 @@ struct Classifier {
                 done_cv.wait(lk, [&]() { return B[b].submitted; });
                 if (gave_up) return false;
             }
-            mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
-            uint16_t *fin, *rows;
-            mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, &fin, &rows);
+            uint16_t *fin, *rows = nullptr;
+            if (dev_ingest) {
+                uint64_t n_dev = 0; uint32_t status = 0;
+                uint32_t *hdr, *len;
+                mc_check(mc_group_text_wait(grp, (uint32_t)(b % nbuf), &n_dev, &status), "mc_group_text_wait");
+                mc_check(mc_group_text_buffers(grp, (uint32_t)(b % nbuf), nullptr, &hdr, &len, &fin), "mc_group_text_buffers");
+                if (status) {          // a batch the card does not vouch for: the whole file goes the host's way
+                    std::lock_guard<std::mutex> lk(done_mu);
+                    gave_up = true; dev_gave_up = true;
+                    done_cv.notify_all();
+                    return false;
+                }
+                Batch &X = B[b];
+                X.n = (size_t)n_dev; X.dev_hdr = hdr; X.dev_len = len;
+                X.own.name_s.resize(X.n); X.own.name_e.resize(X.n); X.own.len.resize(X.n);
+            } else {
+                mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
+                mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, &fin, &rows);
+            }
             Formatted &F = fmt[b];
             F.slice.reset(new Text[nfmt]); F.s_min.assign(nfmt, 0); F.s_max.assign(nfmt, 0); F.s_sum.assign(nfmt, 0);
             F.left = nfmt;
@@ -673,8 +729,9 @@ struct Classifier {
             mc_group_sync(grp);
             mc_group_free_batches(grp);
             std::fclose(fout);
-            if (opt.verbose) std::cerr << (mates ? "streamed ingest of the two files given up (mates out of step, or a range exceeds the guessed buffers); joining the mates first\n"
-                                                 : "streamed ingest given up (a range of the file exceeds the guessed buffers); indexing the whole file\n");
+            if (opt.verbose) std::cerr << (dev_gave_up ? "ingest on the card given up (a record it does not vouch for, or a range that exceeds the guessed buffers); indexing the whole file on the host\n"
+                                           : mates ? "streamed ingest of the two files given up (mates out of step, or a range exceeds the guessed buffers); joining the mates first\n"
+                                                   : "streamed ingest given up (a range of the file exceeds the guessed buffers); indexing the whole file\n");
             return false;
         }
         n_objects = n_done;
@@ -692,7 +749,9 @@ struct Classifier {
         std::fclose(fout);
         if (opt.verbose) {
             if (streamed)
-                std::cerr << "timing: streamed (" << nbatch << (mates ? " byte ranges of both files" : " byte ranges") << ": index | pack+submit | wait+format+write, all overlapped) "
+                std::cerr << "timing: streamed (" << nbatch << (mates ? " byte ranges of both files" : " byte ranges")
+                          << (dev_ingest ? ": copy+submit | records cut, packed and classified on the card | wait+format+write, all overlapped) "
+                                         : ": index | pack+submit | wait+format+write, all overlapped) ")
                           << now() - ts0 << " s\n";
             else
                 std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "
@@ -785,6 +844,8 @@ int main(int argc, char **argv)
         if (val == "--verbose") { o.verbose = true; continue; }
         if (val == "--dump-batches") { o.dump = need("--dump-batches needs a file"); continue; }
         if (val == "--gpu-build") { o.gpu_build = true; continue; }
+        if (val == "--host-ingest") { o.gpu_ingest = false; continue; }
+        if (val == "--gpu-ingest") { o.gpu_ingest = true; continue; }
         die("Failed to recognize option: " + val);
     }
     // reference src/main.cc:214-228
@@ -803,6 +864,7 @@ int main(int argc, char **argv)
     omp_set_num_threads((int)o.cpu);
 #endif
     if (const char *e = getenv("MC_GPU_BUILD")) o.gpu_build = o.gpu_build || atoi(e) != 0;
+    if (const char *e = getenv("MC_GPU_INGEST")) o.gpu_ingest = atoi(e) != 0;
     std::string err;
     if (!read_targets(o.targets, C.T, err)) die(err, -1);
     C.build_if_missing();

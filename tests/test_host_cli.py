@@ -374,7 +374,8 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fastq", "fasta_70", "paired", "paired_drift", "paired_extra_mate", "paired_changed_id", "extended", "gives_up"])
+@pytest.mark.parametrize("mode", ["fastq", "fastq_host", "fasta_70", "paired", "paired_drift", "paired_extra_mate", "paired_changed_id", "extended",
+                                  "gives_up", "gives_up_host", "odd_record"])
 def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     """Large files are cut into byte ranges at record starts and every range is indexed, packed and submitted by
     one task (host/main.cc classify_image, streamed plan; MC_STREAM_MIN_BYTES lowers the size it starts at).  The
@@ -386,7 +387,11 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     record more -- the ranges do not pair up and the mates are joined first, as for small files;
     `paired_changed_id`: the reference's message and exit status; `paired_drift`: the mates of the first half are short,
     those of the second long, so a record's mate is NOT at the same relative place of file 2 (search window cut to 2 KB
-    for the test) and the ranges are paired up by counting records instead"""
+    for the test) and the ranges are paired up by counting records instead.
+    Round 4: plain FASTQ goes to the card as TEXT (mc_text_*: records cut, packed and classified there; `fastq`, `gives_up`);
+    `fastq_host` / `gives_up_host` (MC_GPU_INGEST=0) keep the host's indexer and packer under test; `odd_record`: a header line
+    the card does not vouch for (a name that starts with a blank) -- the batch comes back unclassified and the host does the
+    file; FASTA, mates and the extended table never leave the host path."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import mixed_fasta
@@ -422,24 +427,29 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
         p.write_bytes(text)
         args += ["-O", str(p)]
     else:
-        if mode == "gives_up":
+        if mode.startswith("gives_up"):
             rng = np.random.default_rng(5)
             long_ones = [synth.codes_to_ascii(genomes[i % 4][:4000]) for i in range(300)]
             short_ones = [synth.codes_to_ascii(genomes[i % 4][int(s):int(s) + 40]) for i, s in enumerate(rng.integers(0, 4900, 30000))]
             seqs = long_ones + short_ones
             names = [b"r%d" % i for i in range(len(seqs))]
         text = synth.fastq_text(names, seqs)
+        if mode == "odd_record":
+            text = text.replace(b"@" + names[1500], b"@ " + names[1500], 1)
         p = tmp_path / "reads.fq"
         p.write_bytes(text)
         args += ["-O", str(p)] + (["--extended"] if mode == "extended" else [])
-    r = _run("cuCLARK-l", args, env={"MC_STREAM_MIN_BYTES": "1", "MC_MATE_WINDOW": "2048" if mode == "paired_drift" else "262144"})
+    r = _run("cuCLARK-l", args, env={"MC_STREAM_MIN_BYTES": "1", "MC_MATE_WINDOW": "2048" if mode == "paired_drift" else "262144",
+                                     "MC_GPU_INGEST": "0" if mode.endswith("_host") else "1"})
     if mode == "paired_changed_id":
         assert r.returncode != 0 and "Error: read id does not match between files!" in r.stderr, r.stderr
         return
     assert r.returncode == 0, r.stderr
-    assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up"), r.stderr
+    assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up_host"), r.stderr
+    assert ("ingest on the card given up" in r.stderr) == (mode in ("gives_up", "odd_record")), r.stderr
+    assert ("classified on the card" in r.stderr) == (mode == "fastq"), r.stderr
     assert ("streamed ingest of the two files given up" in r.stderr) == (mode == "paired_extra_mate"), r.stderr
-    assert ("timing: streamed" in r.stderr) == (mode != "gives_up"), r.stderr
+    assert ("timing: streamed" in r.stderr) == (not mode.startswith("gives_up") and mode != "odd_record"), r.stderr
     assert ("byte ranges of both files" in r.stderr) == (mode in ("paired", "paired_drift")), r.stderr
     assert ("mates located by counting records" in r.stderr) == (mode == "paired_drift"), r.stderr
     base = str(dbdir / ("db_central_k27_t4_s%d_m0_light_4.tsk" % ht))
