@@ -534,14 +534,15 @@ def extra_genomes(args, torch, np, dev, dev_index, _genomes):
         kern = sum(a.elapsed_time(b) for a, b in ev) / steps
         res = {"value": round(n_reads * steps / dt / 1e6, 2), "unit": "Mreads/s", "kernel_ms": round(kern, 4), "steps": steps,
                "reads_per_step": n_reads, "n_kmers_db": n_keys,
+               "kernel": ("mc::sk::sk_query_kernel<0, %d>" if info["index_kind"] == 2 else "mc::mz::mz_query_kernel<0, %d>") % (k if k in (31, 27) else 0),
                "index": {"kind": {1: "minimizer", 2: "skm"}.get(info["index_kind"], "lines"),
                          "hbm_bytes_per_kmer": round(info["device_bytes"] / max(1, n_keys), 2),
                          "lines": info["line_end"] - info["line_begin"], "extra_lines": info["n_extra_lines"],
                          "kmers_per_line": round(n_keys / max(1, info["n_lines"]), 2),
                          "lines_overflowing_frac": round(info["n_lines_overflowing"] / max(1, info["line_end"] - info["line_begin"]), 5),
                          "lines_crowded": info["n_lines_crowded"], "largest_line_kmers": info["largest_line"], "hbm_bytes": info["device_bytes"]},
-               "what": "the same kernel, 10 M x 150 bp per launch, on a table whose EVERY k-mer comes from structured genomes "
-                       "(4096 x 1.5 Mb: genera of 4 with shared sequence, a conserved block, tandem repeats, poly-A)"}
+               "what": "10 M x 150 bp per launch on a table whose EVERY k-mer comes from structured genomes (4096 x 1.5 Mb: genera of 4 "
+                       "with shared sequence, a conserved block, tandem repeats, poly-A), on the index MC_INDEX=auto picks for it"}
         # HBM traffic per launch of THIS table, from its own rocprofv3 --pmc passes, if they were taken with these sources
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_genomes.json")))

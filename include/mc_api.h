@@ -247,10 +247,12 @@ int mc_merge_result_device(mc_ctx *ctx, const uint16_t *const *d_srcs, uint32_t 
  * does not start with '@', a name that starts with a blank), bit 1 a line count that is not a multiple of four, bit 2 more
  * reads / containers than allocated -- and the caller packs it on the host (mc_submit).  MC_F_FINAL only. */
 int mc_text_alloc(mc_ctx *ctx, uint32_t n_buffers, uint64_t max_text_bytes, uint64_t max_reads, uint64_t max_containers);
-int mc_text_buffers(mc_ctx *ctx, uint32_t buffer, uint8_t **text, uint32_t **header_offsets, uint32_t **sequence_lengths,
-                    uint16_t **final_rows);
-/* asynchronous: H2D of the text, the ingest kernels and the query kernel are queued; a buffer may be refilled after mc_text_wait */
-int mc_text_submit(mc_ctx *ctx, uint32_t buffer, uint64_t n_bytes);
+/* where the results of a buffer's batch arrive (pinned host memory, valid after mc_text_wait) */
+int mc_text_buffers(mc_ctx *ctx, uint32_t buffer, uint32_t **header_offsets, uint32_t **sequence_lengths, uint16_t **final_rows);
+/* `text` is the caller's own memory (a mapped file will do: it is uploaded from where it lies, on the buffer's own stream --
+ * several threads may submit different buffers at once and their uploads overlap); everything behind the upload is queued.
+ * A buffer takes its next batch after mc_text_wait. */
+int mc_text_submit(mc_ctx *ctx, uint32_t buffer, const uint8_t *text, uint64_t n_bytes);
 int mc_text_wait(mc_ctx *ctx, uint32_t buffer, uint64_t *n_reads, uint32_t *status);
 int mc_text_free(mc_ctx *ctx);
 

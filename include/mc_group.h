@@ -96,9 +96,8 @@ int mc_group_free_batches(mc_group *g);      /* the text buffers below as well *
  * interface), for a group whose members each hold the whole table: buffer b lives on member b % N.  MC_ESTATE for a table
  * that is cut into parts -- the caller then packs on the host as before. */
 int mc_group_text_alloc(mc_group *g, uint32_t n_buffers, uint64_t max_text_bytes, uint64_t max_reads, uint64_t max_containers);
-int mc_group_text_buffers(mc_group *g, uint32_t buffer, uint8_t **text, uint32_t **header_offsets, uint32_t **sequence_lengths,
-                          uint16_t **final_rows);
-int mc_group_text_submit(mc_group *g, uint32_t buffer, uint64_t n_bytes);
+int mc_group_text_buffers(mc_group *g, uint32_t buffer, uint32_t **header_offsets, uint32_t **sequence_lengths, uint16_t **final_rows);
+int mc_group_text_submit(mc_group *g, uint32_t buffer, const uint8_t *text, uint64_t n_bytes);
 int mc_group_text_wait(mc_group *g, uint32_t buffer, uint64_t *n_reads, uint32_t *status);
 
 #ifdef __cplusplus

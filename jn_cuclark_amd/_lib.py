@@ -79,8 +79,8 @@ SYMBOLS = [
     ("mc_result_rows_device", _i, [_vp, _vp, _u64, _vp, _vp]),
     ("mc_merge_result_device", _i, [_vp, C.POINTER(_vp), _u32, _u64, _vp, _vp, _vp]),
     ("mc_text_alloc", _i, [_vp, _u32, _u64, _u64, _u64]),
-    ("mc_text_buffers", _i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
-    ("mc_text_submit", _i, [_vp, _u32, _u64]),
+    ("mc_text_buffers", _i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    ("mc_text_submit", _i, [_vp, _u32, _vp, _u64]),
     ("mc_text_wait", _i, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u32)]),
     ("mc_text_free", _i, [_vp]),
 ]

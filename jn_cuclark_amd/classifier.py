@@ -212,10 +212,10 @@ class CuClarkDB:
         max_containers = int(max_containers or n_bytes // 4 + 64)
         check(self._lib.mc_text_alloc(self._h, 1, max(n_bytes + 1, 16), max_reads, max_containers))
         try:
-            t, h, ln, f = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-            check(self._lib.mc_text_buffers(self._h, 0, C.byref(t), C.byref(h), C.byref(ln), C.byref(f)))
-            _np_view(t.value, np.uint8, n_bytes)[:] = np.frombuffer(text, dtype=np.uint8)
-            check(self._lib.mc_text_submit(self._h, 0, n_bytes))
+            h, ln, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            check(self._lib.mc_text_buffers(self._h, 0, C.byref(h), C.byref(ln), C.byref(f)))
+            arr = np.frombuffer(text, dtype=np.uint8)
+            check(self._lib.mc_text_submit(self._h, 0, arr.ctypes.data, n_bytes))
             n, st = C.c_uint64(), C.c_uint32()
             check(self._lib.mc_text_wait(self._h, 0, C.byref(n), C.byref(st)))
             n = int(n.value)

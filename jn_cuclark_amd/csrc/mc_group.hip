@@ -550,15 +550,15 @@ int mc_group_text_alloc(mc_group *g, uint32_t n_buffers, uint64_t max_text, uint
     }
     return MC_OK;
 }
-int mc_group_text_buffers(mc_group *g, uint32_t buffer, uint8_t **text, uint32_t **hdr, uint32_t **len, uint16_t **fin)
+int mc_group_text_buffers(mc_group *g, uint32_t buffer, uint32_t **hdr, uint32_t **len, uint16_t **fin)
 {
     if (!g) return fail(MC_EINVAL, "group is NULL");
-    return mc_text_buffers(g->ctx[buffer % W(g)], buffer / W(g), text, hdr, len, fin);
+    return mc_text_buffers(g->ctx[buffer % W(g)], buffer / W(g), hdr, len, fin);
 }
-int mc_group_text_submit(mc_group *g, uint32_t buffer, uint64_t n_bytes)
+int mc_group_text_submit(mc_group *g, uint32_t buffer, const uint8_t *text, uint64_t n_bytes)
 {
     if (!g) return fail(MC_EINVAL, "group is NULL");
-    return mc_text_submit(g->ctx[buffer % W(g)], buffer / W(g), n_bytes);
+    return mc_text_submit(g->ctx[buffer % W(g)], buffer / W(g), text, n_bytes);
 }
 int mc_group_text_wait(mc_group *g, uint32_t buffer, uint64_t *n_reads, uint32_t *status)
 {

@@ -26,31 +26,31 @@ using mcint::set_dev;
 
 namespace mcint {
 
-struct TextBuf {                      // pinned, one per host-side buffer
-    uint8_t *text = nullptr;          // max_text + 1 bytes
+// One text batch in flight: everything it needs on the card and, pinned, what comes back.  The text itself is uploaded
+// straight from the caller's (pageable) memory on the buffer's own stream -- measured (tools/ubench/h2d_pageable.hip):
+// hipMemcpyAsync from pageable memory does 20 GB/s from one thread and 50 GB/s from two or more, as much as copies from
+// pinned buffers, while PINNING a ring large enough for whole batches (8 x 400 MB) cost a second per file.
+struct TextBuf {
+    // device
+    uint8_t *text = nullptr;
+    uint32_t *nl = nullptr;           // positions of the newlines
+    uint32_t *blk = nullptr, *off32 = nullptr, *tot = nullptr; uint64_t *base = nullptr;          // scan: newlines per workgroup
+    uint32_t *ncon = nullptr, *coff = nullptr, *ctot = nullptr; uint64_t *cbase = nullptr;        // scan: containers per read
+    uint32_t *d_hdr = nullptr, *d_len = nullptr, *ptr = nullptr, *d_counts = nullptr;
+    uint16_t *con = nullptr, *d_fin = nullptr;
+    // pinned
     uint32_t *hdr = nullptr, *len = nullptr;      // per read: offset of the header line ('@'), bytes of the sequence line
     uint16_t *fin = nullptr;
     uint32_t *counts = nullptr;       // [0] reads, [1] containers, [2] status, [3] lines
-    hipEvent_t ev_up = nullptr, ev_counts = nullptr, ev_done = nullptr;
-    int slot = -1;
+    hipStream_t up = nullptr;         // the upload of this buffer's text
+    hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_counts = nullptr, ev_done = nullptr;
     uint64_t n_bytes = 0;
-    bool submitted = false, fetched = false;
-};
-struct TextSlot {                     // device, two per context
-    uint8_t *text = nullptr;
-    uint32_t *nl = nullptr;           // positions of the newlines
-    uint32_t *blk = nullptr, *off32 = nullptr, *tot = nullptr; uint64_t *base = nullptr;          // scans (newlines per workgroup; containers per read)
-    uint32_t *ncon = nullptr, *coff = nullptr, *ctot = nullptr; uint64_t *cbase = nullptr;
-    int holder = -1;                  // the host buffer whose batch sits in this slot
-    uint32_t *hdr = nullptr, *len = nullptr, *ptr = nullptr, *counts = nullptr;
-    uint16_t *con = nullptr, *fin = nullptr;
-    hipEvent_t ev_free = nullptr;     // the slot's results have been copied out
+    bool submitted = false;
 };
 struct TextState {
     std::vector<TextBuf> bufs;
-    TextSlot slot[2];
-    uint64_t max_text = 0, max_reads = 0, max_con = 0, n_submitted = 0;
-    std::mutex mu;
+    uint64_t max_text = 0, max_reads = 0, max_con = 0;
+    std::mutex mu;                    // the compute and copy-out queues of the context are fed under it
 };
 
 } // namespace mcint
@@ -201,19 +201,13 @@ void text_free(mc_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto &b : T->bufs) {
-        if (b.text) (void)hipHostFree(b.text);
-        if (b.hdr) (void)hipHostFree(b.hdr);
-        if (b.len) (void)hipHostFree(b.len);
-        if (b.fin) (void)hipHostFree(b.fin);
-        if (b.counts) (void)hipHostFree(b.counts);
-        if (b.ev_up) (void)hipEventDestroy(b.ev_up);
-        if (b.ev_counts) (void)hipEventDestroy(b.ev_counts);
-        if (b.ev_done) (void)hipEventDestroy(b.ev_done);
-    }
-    for (auto &s : T->slot) {
-        void *p[] = {s.text, s.nl, s.blk, s.off32, s.tot, s.base, s.ncon, s.coff, s.ctot, s.cbase, s.hdr, s.len, s.ptr, s.counts, s.con, s.fin};
-        for (void *q : p) if (q) (void)hipFree(q);
-        if (s.ev_free) (void)hipEventDestroy(s.ev_free);
+        void *d[] = {b.text, b.nl, b.blk, b.off32, b.tot, b.base, b.ncon, b.coff, b.ctot, b.cbase, b.d_hdr, b.d_len, b.ptr, b.d_counts, b.con, b.d_fin};
+        for (void *q : d) if (q) (void)hipFree(q);
+        void *h[] = {b.hdr, b.len, b.fin, b.counts};
+        for (void *q : h) if (q) (void)hipHostFree(q);
+        hipEvent_t e[] = {b.ev_up, b.ev_k, b.ev_counts, b.ev_done};
+        for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q);
+        if (b.up) (void)hipStreamDestroy(b.up);
     }
     delete T;
     c->text = nullptr;
@@ -243,107 +237,82 @@ int mc_text_alloc(mc_ctx *c, uint32_t n_bufs, uint64_t max_text, uint64_t max_re
     const size_t nblk = (size_t)((max_text + ING_TILE) / ING_TILE) + 1;
     bool ok = true;
     for (auto &b : T->bufs) {
-        ok = ok && hipHostMalloc((void **)&b.text, max_text + 16, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc(&b.text, max_text + 16) == hipSuccess && hipMalloc(&b.nl, nl_cap * 4) == hipSuccess;
+        ok = ok && hipMalloc(&b.blk, nblk * 4) == hipSuccess && hipMalloc(&b.off32, nblk * 4) == hipSuccess && hipMalloc(&b.base, (nblk / 1024 + 4) * 8) == hipSuccess;
+        ok = ok && hipMalloc(&b.tot, (nblk / 1024 + 4) * 4) == hipSuccess && hipMalloc(&b.ctot, ((max_reads + 1) / 1024 + 4) * 4) == hipSuccess;
+        ok = ok && hipMalloc(&b.ncon, (max_reads + 1) * 4) == hipSuccess && hipMalloc(&b.coff, (max_reads + 1) * 4) == hipSuccess;
+        ok = ok && hipMalloc(&b.cbase, ((max_reads + 1) / 1024 + 4) * 8) == hipSuccess;
+        ok = ok && hipMalloc(&b.d_hdr, max_reads * 4) == hipSuccess && hipMalloc(&b.d_len, max_reads * 4) == hipSuccess;
+        ok = ok && hipMalloc(&b.ptr, (max_reads + 1) * 4) == hipSuccess && hipMalloc(&b.d_counts, 16) == hipSuccess;
+        ok = ok && hipMalloc(&b.con, (max_con + 8) * 2) == hipSuccess && hipMalloc(&b.d_fin, max_reads * MC_FINAL_ROW * 2) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b.hdr, max_reads * 4, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b.len, max_reads * 4, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b.fin, max_reads * MC_FINAL_ROW * 2, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b.counts, 16, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&b.ev_up, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&b.ev_counts, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming) == hipSuccess;
-    }
-    for (auto &s : T->slot) {
-        ok = ok && hipMalloc(&s.text, max_text + 16) == hipSuccess && hipMalloc(&s.nl, nl_cap * 4) == hipSuccess;
-        ok = ok && hipMalloc(&s.blk, nblk * 4) == hipSuccess && hipMalloc(&s.off32, nblk * 4) == hipSuccess && hipMalloc(&s.base, (nblk / 1024 + 4) * 8) == hipSuccess;
-        ok = ok && hipMalloc(&s.tot, (nblk / 1024 + 4) * 4) == hipSuccess && hipMalloc(&s.ctot, ((max_reads + 1) / 1024 + 4) * 4) == hipSuccess;
-        ok = ok && hipMalloc(&s.ncon, (max_reads + 1) * 4) == hipSuccess && hipMalloc(&s.coff, (max_reads + 1) * 4) == hipSuccess;
-        ok = ok && hipMalloc(&s.cbase, ((max_reads + 1) / 1024 + 4) * 8) == hipSuccess;
-        ok = ok && hipMalloc(&s.hdr, max_reads * 4) == hipSuccess && hipMalloc(&s.len, max_reads * 4) == hipSuccess;
-        ok = ok && hipMalloc(&s.ptr, (max_reads + 1) * 4) == hipSuccess && hipMalloc(&s.counts, 16) == hipSuccess;
-        ok = ok && hipMalloc(&s.con, (max_con + 8) * 2) == hipSuccess && hipMalloc(&s.fin, max_reads * MC_FINAL_ROW * 2) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&s.ev_free, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&b.up, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.ev_up, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b.ev_k, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.ev_counts, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { (void)hipGetLastError(); text_free(c); return fail(MC_ENOMEM, "text batch buffers: not enough pinned or device memory -- use more, smaller batches (-b)"); }
     return MC_OK;
 }
 
-int mc_text_buffers(mc_ctx *c, uint32_t buf, uint8_t **text, uint32_t **hdr_off, uint32_t **seq_len, uint16_t **final_rows)
+int mc_text_buffers(mc_ctx *c, uint32_t buf, uint32_t **hdr_off, uint32_t **seq_len, uint16_t **final_rows)
 {
     if (!c || !c->text || buf >= c->text->bufs.size()) return fail(MC_EINVAL, "bad text buffer index");
     mcint::TextBuf &b = c->text->bufs[buf];
-    if (text) *text = b.text;
     if (hdr_off) *hdr_off = b.hdr;
     if (seq_len) *seq_len = b.len;
     if (final_rows) *final_rows = b.fin;
     return MC_OK;
 }
 
-// results of the batch in host buffer `buf`: once its counts are on the host, copy exactly its rows and record offsets out
-static int text_fetch(mc_ctx *c, uint32_t buf)
-{
-    mcint::TextState *T = c->text;
-    mcint::TextBuf &b = T->bufs[buf];
-    if (!b.submitted || b.fetched) return MC_OK;
-    mcint::TextSlot &s = T->slot[b.slot];
-    HIPCHK(hipEventSynchronize(b.ev_counts));
-    const uint64_t n = b.counts[2] ? 0 : b.counts[0];
-    if (n) {
-        HIPCHK(hipMemcpyAsync(b.fin, s.fin, n * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipMemcpyAsync(b.hdr, s.hdr, n * 4, hipMemcpyDeviceToHost, c->s_out));
-        HIPCHK(hipMemcpyAsync(b.len, s.len, n * 4, hipMemcpyDeviceToHost, c->s_out));
-    }
-    HIPCHK(hipEventRecord(b.ev_done, c->s_out));
-    HIPCHK(hipEventRecord(s.ev_free, c->s_out));
-    b.fetched = true;
-    if (s.holder == (int)buf) s.holder = -1;
-    return MC_OK;
-}
-
-int mc_text_submit(mc_ctx *c, uint32_t buf, uint64_t n_bytes)
+int mc_text_submit(mc_ctx *c, uint32_t buf, const uint8_t *text, uint64_t n_bytes)
 {
     if (!c || !c->text || buf >= c->text->bufs.size()) return fail(MC_EINVAL, "bad text buffer index");
     if (!c->db_loaded) return fail(MC_ESTATE, "mc_text_submit before a database was loaded");
+    if (n_bytes && !text) return fail(MC_EINVAL, "text is NULL");
     mcint::TextState *T = c->text;
     if (n_bytes > T->max_text) return fail(MC_EINVAL, "text batch larger than allocated");
     int rc = set_dev(c); if (rc) return rc;
-    std::lock_guard<std::mutex> lk(T->mu);
     mcint::TextBuf &b = T->bufs[buf];
-    const int si = (int)(T->n_submitted++ & 1u);
-    mcint::TextSlot &s = T->slot[si];
-    if (s.holder >= 0) { rc = text_fetch(c, (uint32_t)s.holder); if (rc) return rc; }      // the slot's previous batch leaves first
-    b.slot = si; b.submitted = true; b.fetched = false;
-    s.holder = (int)buf;
-    if (n_bytes && b.text[n_bytes - 1] != '\n') b.text[n_bytes++] = '\n';           // (a file that ends without a newline)
+    if (b.submitted) return fail(MC_ESTATE, "text buffer resubmitted before mc_text_wait");
+    // the upload: on this buffer's own stream, from the caller's memory, outside the lock -- several threads upload at once
+    if (n_bytes) HIPCHK(hipMemcpyAsync(b.text, text, n_bytes, hipMemcpyHostToDevice, b.up));
+    if (n_bytes && text[n_bytes - 1] != '\n') {                       // a file that ends without a newline
+        HIPCHK(hipMemsetAsync(b.text + n_bytes, '\n', 1, b.up));
+        n_bytes++;
+    }
+    HIPCHK(hipEventRecord(b.ev_up, b.up));
     b.n_bytes = n_bytes;
+    std::lock_guard<std::mutex> lk(T->mu);
+    b.submitted = true;
     hipStream_t st = c->streams[0];
-    HIPCHK(hipStreamWaitEvent(c->s_in, s.ev_free, 0));               // the slot's previous results are out
-    if (n_bytes) HIPCHK(hipMemcpyAsync(s.text, b.text, n_bytes, hipMemcpyHostToDevice, c->s_in));
-    HIPCHK(hipEventRecord(b.ev_up, c->s_in));
     HIPCHK(hipStreamWaitEvent(st, b.ev_up, 0));
     const uint64_t nl_cap = 4 * T->max_reads + 4;
     // newlines: per workgroup -> offsets -> positions
     const uint32_t nblk = (uint32_t)((n_bytes + ING_TILE - 1) / ING_TILE) + 1u;
     const uint32_t nb2 = (nblk + 1023u) / 1024u;
-    hipLaunchKernelGGL(ing_count_kernel, dim3(nblk), dim3(ING_THREADS), 0, st, s.text, n_bytes, s.blk);
-    hipLaunchKernelGGL(mc::sk::sk_scan_kernel, dim3(nb2), dim3(mc::RL_THREADS), 0, st, s.blk, (uint64_t)nblk, s.off32, s.tot);
-    hipLaunchKernelGGL(mc::sk::sk_scan_blocks_kernel, dim3(1), dim3(256), 0, st, s.tot, nb2, s.base);
-    hipLaunchKernelGGL(ing_scatter_kernel, dim3(nblk), dim3(ING_THREADS), 0, st, s.text, n_bytes, s.off32, s.base, s.nl, nl_cap);
-    hipLaunchKernelGGL(ing_begin_kernel, dim3(1), dim3(1), 0, st, s.base + nb2, nl_cap, T->max_reads, s.counts);
+    hipLaunchKernelGGL(ing_count_kernel, dim3(nblk), dim3(ING_THREADS), 0, st, b.text, n_bytes, b.blk);
+    hipLaunchKernelGGL(mc::sk::sk_scan_kernel, dim3(nb2), dim3(mc::RL_THREADS), 0, st, b.blk, (uint64_t)nblk, b.off32, b.tot);
+    hipLaunchKernelGGL(mc::sk::sk_scan_blocks_kernel, dim3(1), dim3(256), 0, st, b.tot, nb2, b.base);
+    hipLaunchKernelGGL(ing_scatter_kernel, dim3(nblk), dim3(ING_THREADS), 0, st, b.text, n_bytes, b.off32, b.base, b.nl, nl_cap);
+    hipLaunchKernelGGL(ing_begin_kernel, dim3(1), dim3(1), 0, st, b.base + nb2, nl_cap, T->max_reads, b.d_counts);
     // records -> containers per read -> offsets -> packed reads
     const uint32_t g = (uint32_t)std::min<uint64_t>((T->max_reads + 256) / 256, (uint64_t)c->n_cu * 32);
-    hipLaunchKernelGGL(ing_records_kernel, dim3(g), dim3(256), 0, st, s.text, s.nl, c->k, T->max_reads, s.counts, s.hdr, s.len, s.ncon);
+    hipLaunchKernelGGL(ing_records_kernel, dim3(g), dim3(256), 0, st, b.text, b.nl, c->k, T->max_reads, b.d_counts, b.d_hdr, b.d_len, b.ncon);
     const uint32_t nr1 = (uint32_t)(T->max_reads + 1), nb3 = (nr1 + 1023u) / 1024u;
-    hipLaunchKernelGGL(mc::sk::sk_scan_kernel, dim3(nb3), dim3(mc::RL_THREADS), 0, st, s.ncon, (uint64_t)nr1, s.coff, s.ctot);
-    hipLaunchKernelGGL(mc::sk::sk_scan_blocks_kernel, dim3(1), dim3(256), 0, st, s.ctot, nb3, s.cbase);
-    hipLaunchKernelGGL(ing_pack_kernel, dim3(g), dim3(256), 0, st, s.text, s.nl, c->k, T->max_con, s.counts, s.coff, s.cbase, s.ptr, s.con);
+    hipLaunchKernelGGL(mc::sk::sk_scan_kernel, dim3(nb3), dim3(mc::RL_THREADS), 0, st, b.ncon, (uint64_t)nr1, b.coff, b.ctot);
+    hipLaunchKernelGGL(mc::sk::sk_scan_blocks_kernel, dim3(1), dim3(256), 0, st, b.ctot, nb3, b.cbase);
+    hipLaunchKernelGGL(ing_pack_kernel, dim3(g), dim3(256), 0, st, b.text, b.nl, c->k, T->max_con, b.d_counts, b.coff, b.cbase, b.ptr, b.con);
     HIPCHK(hipGetLastError());
     // classification, reads and containers counted on the device
-    rc = mcint::launch_query(c, s.ptr, s.con, T->max_reads, T->max_con, MC_F_FINAL, s.fin, nullptr, st, s.counts);
+    rc = mcint::launch_query(c, b.ptr, b.con, T->max_reads, T->max_con, MC_F_FINAL, b.d_fin, nullptr, st, b.d_counts);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(b.ev_counts, st));          // (first as "the kernels are done" ...)
-    HIPCHK(hipStreamWaitEvent(c->s_out, b.ev_counts, 0));
-    HIPCHK(hipMemcpyAsync(b.counts, s.counts, 16, hipMemcpyDeviceToHost, c->s_out));
-    HIPCHK(hipEventRecord(b.ev_counts, c->s_out));    // (... then as "the counts are on the host")
+    HIPCHK(hipEventRecord(b.ev_k, st));
+    HIPCHK(hipStreamWaitEvent(c->s_out, b.ev_k, 0));
+    HIPCHK(hipMemcpyAsync(b.counts, b.d_counts, 16, hipMemcpyDeviceToHost, c->s_out));
+    HIPCHK(hipEventRecord(b.ev_counts, c->s_out));
     return MC_OK;
 }
 
@@ -354,13 +323,19 @@ int mc_text_wait(mc_ctx *c, uint32_t buf, uint64_t *n_reads, uint32_t *status)
     mcint::TextBuf &b = T->bufs[buf];
     if (!b.submitted) return fail(MC_ESTATE, "text batch was never submitted");
     int rc = set_dev(c); if (rc) return rc;
+    HIPCHK(hipEventSynchronize(b.ev_counts));
+    const uint64_t n = b.counts[2] ? 0 : b.counts[0];
     {
-        std::lock_guard<std::mutex> lk(T->mu);
-        rc = text_fetch(c, buf);
-        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(T->mu);          // exactly the rows and record offsets of this batch
+        if (n) {
+            HIPCHK(hipMemcpyAsync(b.fin, b.d_fin, n * MC_FINAL_ROW * 2, hipMemcpyDeviceToHost, c->s_out));
+            HIPCHK(hipMemcpyAsync(b.hdr, b.d_hdr, n * 4, hipMemcpyDeviceToHost, c->s_out));
+            HIPCHK(hipMemcpyAsync(b.len, b.d_len, n * 4, hipMemcpyDeviceToHost, c->s_out));
+        }
+        HIPCHK(hipEventRecord(b.ev_done, c->s_out));
     }
     HIPCHK(hipEventSynchronize(b.ev_done));
-    if (n_reads) *n_reads = b.counts[2] ? 0 : b.counts[0];
+    if (n_reads) *n_reads = n;
     if (status) *status = b.counts[2];
     b.submitted = false;
     return MC_OK;

@@ -130,8 +130,11 @@ struct Options {
     const char *targets = nullptr, *folder = nullptr, *objects = nullptr, *objects2 = nullptr, *results = nullptr;
     const char *dump = nullptr;      // test hook: write the packed batches here
     bool gpu_build = false;          // --gpu-build / MC_GPU_BUILD=1: build a missing database on the GPU
-    bool gpu_ingest = true;          // large plain FASTQ files: the card cuts and packs the records (mc_text_*); --host-ingest /
-                                     // MC_GPU_INGEST=0: the host does, as for every other input
+    bool gpu_ingest = false;         // --gpu-ingest / MC_GPU_INGEST=1: large plain FASTQ files go to the card as TEXT, which cuts and
+                                     // packs the records itself (mc_text_*).  Off by default: measured at the metric's size (40 M reads,
+                                     // 12.7 GB, 16 threads) it is no faster than the host's indexer and packer -- 50-71 against 63-83
+                                     // M reads/s: uploading 317 bytes of text per read from the page cache costs the host as many
+                                     // thread-seconds as parsing them into 44
 };
 
 struct Classifier {
@@ -319,7 +322,13 @@ struct Classifier {
         std::thread early_alloc;
         int early_rc = MC_OK;
         std::string early_err;
-        const size_t nbatch_g = std::max<size_t>(1, opt.batches);
+        size_t nbatch_g = std::max<size_t>(1, opt.batches);
+        // (card ingest: ranges of about MC_TEXT_RANGE_MB of text -- the first batch is up after a few milliseconds, and a ring of
+        // a dozen buffers keeps uploads, kernels and the formatting of earlier batches going side by side)
+        size_t text_range = 48u << 20;
+        if (const char *e = getenv("MC_TEXT_RANGE_MB")) { const long v = atol(e); if (v >= 1 && v <= 2048) text_range = (size_t)v << 20; }
+        const bool card_wanted = streamed && opt.gpu_ingest && map[0] == '@' && !mates && !opt.ext && !opt.dump && text_path;
+        if (card_wanted) nbatch_g = std::max(nbatch_g, (nb + text_range - 1) / text_range);
         if (nb >= (8u << 20) || streamed) {
             ReadIndex H;
             std::string herr;
@@ -330,10 +339,10 @@ struct Classifier {
                 const double con_per_read = (double)container_bound(H, 0, hn, (unsigned)opt.k) / (double)hn;
                 guess_reads = (size_t)((double)nb / per_read / (double)nbatch_g * 1.10) + 64;
                 guess_con = (size_t)((double)guess_reads * con_per_read * (mates ? 2.2 : 1.05)) + 64;      // (a mate of its own per read)
-                guess_nbuf = std::min(nbatch_g, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
+                guess_nbuf = std::min(nbatch_g, std::max<size_t>(2, std::min<size_t>(opt.cpu, card_wanted ? 12 : 8)));
                 // (plain FASTQ, streamed, final rows only: the card cuts and packs the records -- its buffers are allocated below,
                 // once the byte ranges are known)
-                dev_ingest = streamed && opt.gpu_ingest && map[0] == '@' && !mates && !opt.ext && !opt.dump && guess_con <= 0xFFFFFFFFull && text_path;
+                dev_ingest = card_wanted && guess_con <= 0xFFFFFFFFull;
                 if (guess_con <= 0xFFFFFFFFull && !dev_ingest)
                     early_alloc = std::thread([&]() {
                         early_rc = mc_group_alloc_batches(grp, (uint32_t)guess_nbuf, guess_reads, guess_con, opt.ext ? 1 : 0);
@@ -439,6 +448,7 @@ struct Classifier {
         std::mutex submit_mu, done_mu;
         std::condition_variable done_cv;
         bool buffers_ready = !streamed, gave_up = false, dev_gave_up = false;        // under done_mu
+        double t_alloc = 0.0, t_submit = 0.0, t_wait = 0.0;                     // card ingest: seconds inside mc_group_text_submit (all tasks) / _wait (main thread)
         auto index_batch = [&](size_t b) {
             Batch &X = B[b];
             std::string ierr;
@@ -480,13 +490,10 @@ struct Classifier {
                 stop = gave_up;
             }
             if (!stop && dev_ingest) {
-                const uint32_t buf = (uint32_t)(b % nbuf);
-                uint8_t *dst;
-                mc_check(mc_group_text_buffers(grp, buf, &dst, nullptr, nullptr, nullptr), "mc_group_text_buffers");
-                const size_t len = cut[b + 1] - cut[b];
-                std::memcpy(dst, map + cut[b], len);
-                std::lock_guard<std::mutex> lk(submit_mu);
-                mc_check(mc_group_text_submit(grp, buf, len), "mc_group_text_submit");
+                // the bytes go up from where the file is mapped, on the buffer's own queue: several tasks upload at once
+                const double t_a = now();
+                mc_check(mc_group_text_submit(grp, (uint32_t)(b % nbuf), map + cut[b], cut[b + 1] - cut[b]), "mc_group_text_submit");
+                { std::lock_guard<std::mutex> lk(done_mu); t_submit += now() - t_a; }
             } else if (!stop) {
                 const uint32_t buf = (uint32_t)(b % nbuf);
                 uint32_t *ptr; uint16_t *con;
@@ -507,6 +514,7 @@ struct Classifier {
             for (size_t b = 0; b < nbuf; b++) pool.run([&, b]() { index_batch(b); pack_batch(b); });
             for (size_t b = nbuf; b < nbatch; b++) pool.run([&, b]() { index_batch(b); });
             early_alloc.join();
+            t_alloc = now();
             if (early_rc != MC_OK) die(std::string(dev_ingest ? "mc_group_text_alloc: " : "mc_group_alloc_batches: ") + early_err);
             { std::lock_guard<std::mutex> lk(done_mu); buffers_ready = true; }
             done_cv.notify_all();
@@ -667,8 +675,10 @@ struct Classifier {
             if (dev_ingest) {
                 uint64_t n_dev = 0; uint32_t status = 0;
                 uint32_t *hdr, *len;
+                const double t_a = now();
                 mc_check(mc_group_text_wait(grp, (uint32_t)(b % nbuf), &n_dev, &status), "mc_group_text_wait");
-                mc_check(mc_group_text_buffers(grp, (uint32_t)(b % nbuf), nullptr, &hdr, &len, &fin), "mc_group_text_buffers");
+                t_wait += now() - t_a;
+                mc_check(mc_group_text_buffers(grp, (uint32_t)(b % nbuf), &hdr, &len, &fin), "mc_group_text_buffers");
                 if (status) {          // a batch the card does not vouch for: the whole file goes the host's way
                     std::lock_guard<std::mutex> lk(done_mu);
                     gave_up = true; dev_gave_up = true;
@@ -694,9 +704,12 @@ struct Classifier {
             return true;
         };
         size_t n_done = 0;
-        bool ok = launch_format(0);
+        // batch b+1 is formatted while batch b is written (card ingest, whose batches are small: up to four ahead)
+        const size_t ahead = dev_ingest ? 4 : 1;
+        size_t launched = 0;
+        bool ok = launch_format(launched++);
         for (size_t b = 0; ok && b < nbatch; b++) {
-            if (b + 1 < nbatch && !launch_format(b + 1)) { ok = false; }   // batch b+1 is formatted while batch b is written
+            while (ok && launched < nbatch && launched <= b + ahead && launched < b + nbuf) { if (!launch_format(launched)) ok = false; else launched++; }
             { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return fmt[b].left == 0; }); }
             if (!ok) break;
             if (b + nbuf < nbatch) enqueue_pack(b + nbuf);      // this batch's buffers are free again
@@ -752,7 +765,8 @@ struct Classifier {
                 std::cerr << "timing: streamed (" << nbatch << (mates ? " byte ranges of both files" : " byte ranges")
                           << (dev_ingest ? ": copy+submit | records cut, packed and classified on the card | wait+format+write, all overlapped) "
                                          : ": index | pack+submit | wait+format+write, all overlapped) ")
-                          << now() - ts0 << " s\n";
+                          << now() - ts0 << " s"
+                          << (dev_ingest ? " (in mc_group_text_submit, all tasks: " + std::to_string(t_submit) + " s; main thread in mc_group_text_wait: " + std::to_string(t_wait) + " s; buffers ready after " + std::to_string(t_alloc - ts0) + " s)" : std::string()) << "\n";
             else
                 std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "
                           << now() - ts2 << " s\n";

@@ -53,5 +53,5 @@ rm -rf $OUT/trace/*/*kernel_trace.csv
 cat $OUT/kernel_stats_query.csv; cat $OUT/pmc_query.txt
 # (NO_TRAFFIC=1: a profile of another workload must not replace the headline's traffic figure)
 if [ -z "${NO_TRAFFIC:-}" ]; then
-python3 tools/update_traffic.py $OUT/pmc_query.txt $OUT/bench_trace.json > $OUT/traffic.json && cp profiles/traffic.json $OUT/traffic_profiles.json
+python3 tools/update_traffic.py $OUT/pmc_query.txt $OUT/bench_trace.json > $OUT/traffic.json
 fi

@@ -17,8 +17,10 @@ for ln in open(sys.argv[1]):
         vals[p[0]] = float(p[2].split("=")[1])
 line = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
-line_bytes = 128 if line["roofline"]["index"] == "minimizer" else 64
-# MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes
+line_bytes = 128 if line["roofline"]["index"] in ("minimizer", "skm") else 64
+# MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes.  (The super-k-mer kernel asks for its
+# 128-byte lines in two 64-byte halves: the second half hits in L2, the miss brings in the whole line -- TCC_EA0_RDREQ counts one
+# request per line and FETCH_SIZE 64 bytes for it: the same factor, cross-checked by RDREQ x 128 B.)
 hbm = (2.0 if line_bytes == 128 else 1.0) * fetch_kb * 1024 + write_kb * 1024
 out = {
     "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, average per launch of %s)" % (
@@ -32,5 +34,7 @@ out = {
     "correction": "FETCH_SIZE x 2 for 128-byte requests (MI355X_MICROARCH.md, HBM section: gfx950 tallies a 128-byte request as "
                   "64 bytes), cross-checked by TCC_EA0_RDREQ x 128 B; 64-byte requests (bucket-line kernel) are exact.",
 }
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+# (a profile of the genome-shaped table -- bench.py --db genomes -- goes to its own file: the `genomes` key of the bench line reads it)
+name = "traffic_genomes.json" if out["db"] == "genomes" else "traffic.json"
+json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
 print(json.dumps(out))
