@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MC_API_VERSION 2
+#define MC_API_VERSION 3   /* 3 (round 4): mc_text_*, mc_group_text_*, MC_INDEX_SUPERKMER; nothing removed or changed */
 
 enum {
     MC_OK          =  0,
