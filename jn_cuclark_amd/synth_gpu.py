@@ -377,6 +377,9 @@ def host_driver_run(exe, work, k, n_targets, fastq, n_reads, threads=16, batches
         if not os.path.exists(p):
             with open(p, "w") as f:
                 f.write(">g%04d\n" % i)
+    for old in (os.path.join(work, "res.csv"),):          # (a result file left by an earlier run is not this run's to truncate: 1.7 GB of page cache)
+        if os.path.exists(old):
+            os.remove(old)
     t0 = _t.time()
     inputs = ["-P", fastq, fastq2] if fastq2 else ["-O", fastq]          # -P: paired-end mates in two files (src/main.cc:43-69)
     r = subprocess.run([exe, "-k", str(k), "-T", os.path.join(work, "targets.txt"), "-D", work] + inputs + ["-R", os.path.join(work, "res"),
