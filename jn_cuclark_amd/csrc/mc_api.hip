@@ -103,7 +103,7 @@ void index_abort(mc_ctx *c)
     if (c->build.d_cursor) (void)hipFree(c->build.d_cursor);
     if (c->build.d_off32) (void)hipFree(c->build.d_off32);
     if (c->build.d_blk_base) (void)hipFree(c->build.d_blk_base);
-    if (c->build.d_entries) (void)hipFree(c->build.d_entries);
+    if (c->build.d_entries) { if (c->build.entries_on_host) (void)hipHostFree(c->build.d_entries); else (void)hipFree(c->build.d_entries); }
     if (c->build.d_count_mz) (void)hipFree(c->build.d_count_mz);
     c->build = mcint::IndexBuild();
 }
@@ -546,11 +546,25 @@ int sk_next_pass(mc_ctx *c)
     int rc = sk_scan(c, B.d_count, B.sk_n_fine, B.d_off32, B.d_blk_base, &total);
     if (rc) return rc;
     B.sk_n_entries = total;
-    if (hipMalloc(&B.d_entries, (size_t)(total ? total : 1) * sizeof(mc::sk::SkSlot)) != hipSuccess) {
-        (void)hipGetLastError();
-        free_db(c); index_abort(c);
-        return fail(MC_ENOMEM, "super-k-mer index: not enough HBM for " + std::to_string(total) + " entries of 16 bytes while it is built");
+    // The entries (16 bytes per stored k-mer) live until the lines are written, NEXT TO the lines: on a card they would crowd
+    // (more than 45 % of what is free: the lines of a genome-shaped table take 9-16 bytes per k-mer themselves) they go to pinned
+    // host memory instead, written once and read once over PCIe -- slower to build, and a table of 12e9 instead of 8e9 k-mers
+    // per card.  MC_SKM_ENTRIES=host|device forces either.
+    const size_t ebytes = (size_t)(total ? total : 1) * sizeof(mc::sk::SkSlot);
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    const char *where = getenv("MC_SKM_ENTRIES");
+    bool on_host = where ? !strcmp(where, "host") : (double)ebytes > 0.45 * (double)fr;
+    if (!on_host && hipMalloc(&B.d_entries, ebytes) != hipSuccess) { (void)hipGetLastError(); B.d_entries = nullptr; on_host = !(where && !strcmp(where, "device")); }
+    if (on_host && !B.d_entries) {
+        if (hipHostMalloc(&B.d_entries, ebytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); B.d_entries = nullptr; }
+        else B.entries_on_host = true;
     }
+    if (!B.d_entries) {
+        free_db(c); index_abort(c);
+        return fail(MC_ENOMEM, "super-k-mer index: neither HBM nor pinned host memory for " + std::to_string(total) + " entries of 16 bytes while it is built");
+    }
+    if (B.entries_on_host && getenv("MC_SKM_VERBOSE")) fprintf(stderr, "libmcclark: super-k-mer index: %.1f GB of entries in pinned host memory\n", (double)ebytes / 1e9);
     HIPCHK(hipMemsetAsync(B.d_cursor, 0, (size_t)B.sk_n_fine * 4, st));
     HIPCHK(hipStreamSynchronize(st));
     B.pass = 1;

@@ -84,6 +84,7 @@ struct IndexBuild {
     uint32_t *d_cursor = nullptr, *d_off32 = nullptr;
     uint64_t *d_blk_base = nullptr;
     void *d_entries = nullptr;
+    bool entries_on_host = false;      // the entries did not fit next to the lines they turn into: pinned host memory, written and read over PCIe
     uint64_t sk_n_entries = 0;
 };
 

@@ -245,3 +245,16 @@ def test_file_loader_builds_the_records_from_sz_ky_lb(gpu, oracle, tmp_path):
         got, rows = db.classify(rp, con, extended=True)
     assert info["index_kind"] == 2 and info["n_keys"] == ky.size
     assert np.array_equal(rows, want_rows) and np.array_equal(got, oracle.result_rows(want_rows))
+
+
+def test_entries_of_the_build_in_host_memory(gpu, oracle, monkeypatch):
+    """a table whose entries would crowd the card is built with its entries in pinned host memory (MC_SKM_ENTRIES=host forces
+    it): the same lines"""
+    k = 31
+    genomes, sz, ky, lb = small_db(k=k, glen=6000)
+    codes, _ = synth.sample_reads(genomes, 2000, 150, seed=21)
+    rp, con = synth.pack_uniform(codes)
+    info_dev, _ = _check(gpu, oracle, k, sz, ky, lb, rp, con, 6)
+    monkeypatch.setenv("MC_SKM_ENTRIES", "host")
+    info_host, _ = _check(gpu, oracle, k, sz, ky, lb, rp, con, 6)
+    assert info_host == info_dev
