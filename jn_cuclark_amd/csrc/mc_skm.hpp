@@ -873,30 +873,11 @@ void sk_query_kernel(const SkArgs A)
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        SK_MARK(12);
-                        // ... (5) and lane r < nb turns run r into what the records are asked: key hash, offsets, flanks, line
-                        {
-                            const uint32_t r = opaque(lane) & (uint32_t)(SK_RUNS - 1);
-                            const u32x4 raw = desc[r];
-                            const uint32_t ea = endv[raw[2] & 127u], eb = endv[raw[3] & 127u];
-                            const uint64_t Kr = ((uint64_t)raw[1] << 32) | raw[0];
-                            const SkRun R = sk_run(Kr, base + raw[2], base + raw[3], ea, eb);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            // (entries behind the batch's last run: the last run's line -- fetched anyway -- and an empty range of
-                            // offsets: the lane groups past the last run match nothing, without a test)
-                            const uint32_t ln = sk_line_of(Kr, A.n_lines);
-                            const uint32_t ln_last = lane_bcast(ln, nb - 1u);
-                            const bool real = __builtin_amdgcn_inverse_ballot_w64(mask_lt_s(r, nb));
-                            if (lane < (uint32_t)SK_RUNS)
-                                desc[r] = u32x4{R.kd0, real ? (R.kd1 | (R.o_lo << 20) | (R.o_hi << 24)) : (15u << 20), R.lr, real ? ln : ln_last};
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
                         SK_MARK(13);
-                        // (6) FOUR lanes fetch the line of a run, two slots each (lane q of the four: slots q and q + 4 -- the build
+                        // (5) FOUR lanes fetch the line of a run, two slots each (lane q of the four: slots q and q + 4 -- the build
                         //     puts the records of one minimizer into neighbouring slots, so they sit in different lanes); 16 runs a
-                        //     round, every round in flight before any is used
+                        //     round, every round in flight before any is used.  The line comes straight from the run's key: the loads
+                        //     are on their way while (6) works out what the records will be asked.
                         constexpr int ROUNDS = SK_RUNS / 16;
                         u32x4 va[ROUNDS], vb[ROUNDS];
                         const uint32_t lf = opaque(lane);
@@ -906,10 +887,11 @@ void sk_query_kernel(const SkArgs A)
                         for (int rd = 0; rd < ROUNDS; rd++) {
                             if (16u * rd < nb) {
                                 const uint32_t j = 16u * rd + (lf >> 2);
+                                const uint64_t Kj = *reinterpret_cast<const uint64_t *>(desc + (j < last ? j : last));      // (lane groups past the last run: its line again)
 #ifdef MC_SK_DEBUG_WINDOW      // measurement builds only (WRONG results): every fetch inside a cache-resident window of lines
-                                const uint32_t ln = reinterpret_cast<const uint32_t *>(desc + j)[3] & (uint32_t)(MC_SK_DEBUG_WINDOW - 1);
+                                const uint32_t ln = sk_line_of(Kj, A.n_lines) & (uint32_t)(MC_SK_DEBUG_WINDOW - 1);
 #else
-                                const uint32_t ln = reinterpret_cast<const uint32_t *>(desc + j)[3];
+                                const uint32_t ln = sk_line_of(Kj, A.n_lines);
 #endif
                                 uint64_t addr;              // lane_base + ln * 128 in one operation
                                 asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(addr) : "v"(ln), "s"(128u), "v"(lane_base) : "vcc");
@@ -917,6 +899,24 @@ void sk_query_kernel(const SkArgs A)
                                 vb[rd] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>((uintptr_t)addr + 64u));
                             }
                         }
+                        SK_MARK(12);
+                        // (6) lane r < nb turns run r into what the records are asked: key hash, offsets, flanks
+                        {
+                            const uint32_t r = opaque(lane) & (uint32_t)(SK_RUNS - 1);
+                            const u32x4 raw = desc[r];
+                            const uint32_t ea = endv[raw[2] & 127u], eb = endv[raw[3] & 127u];
+                            const uint64_t Kr = ((uint64_t)raw[1] << 32) | raw[0];
+                            const SkRun R = sk_run(Kr, base + raw[2], base + raw[3], ea, eb);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            // (entries behind the batch's last run: an empty range of offsets -- the lane groups past the last run
+                            // match nothing, without a test)
+                            const bool real = __builtin_amdgcn_inverse_ballot_w64(mask_lt_s(r, nb));
+                            if (lane < (uint32_t)SK_RUNS)
+                                desc[r] = u32x4{R.kd0, real ? (R.kd1 | (R.o_lo << 20) | (R.o_hi << 24)) : (15u << 20), R.lr, 0u};
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
                         SK_MARK(14);
                         // (7) a lane looks for the run's minimizer in its two slots and works the flanks out for the one that has it
                         //     (both: a second turn, rare); what a lane finds over the rounds is added up as long as it is one target's
