@@ -690,8 +690,9 @@ int sk_end(mc_ctx *c)
     if (occ < 1) occ = 1;
     // a persistent grid of 7 workgroups per CU although 8 fit (measured, genome-shaped table, one box, twice each:
     // 8 / 7 / 6 / 5 / 4 per CU -> 7.47 / 6.68 / 6.73 / 6.77 / 7.14 ms per 10 M reads)
+    const int fits = occ;
     if (occ > 7) occ = 7;
-    if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v < occ) occ = v; }
+    if (const char *e = getenv("MC_GRID_OCC")) { const int v = atoi(e); if (v >= 1 && v <= fits) occ = v; }
     c->grid_blocks = occ * c->n_cu;
     c->db_loaded = true;
     return MC_OK;
