@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define MC_API_VERSION 3   /* 3 (round 4): mc_text_*, mc_group_text_*, MC_INDEX_SUPERKMER; nothing removed or changed */
+#define MC_API_VERSION 4   /* 3 (round 4): mc_text_*, mc_group_text_*, MC_INDEX_SUPERKMER; 4: database cycles (mc_group_set_cycle,
+                              MC_F_FOLLOWUP, two fields at the end of mc_group_info); nothing removed or changed */
 
 enum {
     MC_OK          =  0,
@@ -57,6 +58,8 @@ typedef struct mc_ctx mc_ctx;
 /* flags of mc_submit / mc_query_device */
 #define MC_F_FINAL    1u   /* produce the 5-u16 final rows (the fused query+top-2 path) */
 #define MC_F_ROWS     2u   /* produce sparse rows [n, t0,h0, ...] (--extended, shards)  */
+#define MC_F_FOLLOWUP 4u   /* mc_group_submit only: the batch's sparse-row buffer holds the rows of earlier database cycles;
+                              they are merged with this cycle's (queryBatch(.., followup), CuClarkDB.cu:932-948) */
 
 typedef struct mc_db_info {
     uint64_t htsize;          /* total buckets of the table                         */

@@ -52,6 +52,9 @@ typedef struct mc_group_info {
     uint32_t n_shards;         /* S: parts the table is cut into (1 = replicas)                    */
     uint32_t n_groups;         /* G: groups of S members that each hold the whole table; batches are dealt round-robin
                                   over the groups, rows are exchanged inside a group; S * G <= n_members              */
+    uint32_t n_cycles;         /* C: 1 = the table is resident; > 1: it is larger than all devices together and cut into
+                                  C * n_members parts, of which the members hold n_members at a time (mc_group_set_cycle)  */
+    uint32_t cycle;            /* the cycle whose parts are loaded now                                                  */
 } mc_group_info;
 
 /* replaces: CuClarkDB::CuClarkDB device discovery + peer access (CuClarkDB.cu:118-215).
@@ -72,11 +75,20 @@ int mc_group_close(mc_group *g);
  * AUTO that finds its estimate too kind (MC_ENOMEM while loading) cuts the table into more parts and tries again;
  * when the minimizer lines fit in no cut, the bucket-line table is the last resort (whole on every member when it fits
  * one, else the reference's bucket ranges, CuClarkDB.cu:552-559; mc_db_info.index_fallback = 1, said on stderr).
- * A table LARGER THAN ALL DEVICES TOGETHER IS REFUSED (MC_ENOMEM, "use more devices"): the reference would cycle
- * database parts through the devices and re-query every batch per cycle (swapDbParts, CuClarkDB.cu:775-815,
- * src/CuCLARK_hh.hh:1765-1772) -- there is no such cycling here; 8 x 288 GB hold about 90e9 k-mers. */
+ * A table LARGER THAN ALL DEVICES TOGETHER is cut into C * N parts (by minimizer, as above) of which the N members hold N
+ * at a time: cycle 0 is loaded here, mc_group_info.n_cycles says C, and the caller classifies every batch once per
+ * cycle (mc_group_set_cycle, MC_F_FOLLOWUP) -- the reference's swapDbParts loop (CuClarkDB.cu:775-815,
+ * src/CuCLARK_hh.hh:1765-1772); every change of cycle reads the database files again.  MC_GROUP_CYCLES=C forces C cycles
+ * (tests).  More than 15 members, a table without a minimizer index, or parts that fit in no number of cycles up to 64:
+ * MC_ENOMEM, "use more devices". */
 int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t sampling, int mode);
 int mc_group_get_info(mc_group *g, mc_group_info *out);
+/* replaces: CuClarkDB::swapDbParts (CuClarkDB.cu:775-815).  Loads the parts of cycle `cycle` (0 <= cycle < n_cycles) into the
+ * members; nothing happens when they are loaded already.  All submitted batches must have been waited for.  The protocol of a
+ * file (src/CuCLARK_hh.hh:1737-1772): cycle 0, every batch with MC_F_ROWS; cycle c > 0, every batch again with
+ * MC_F_ROWS | MC_F_FOLLOWUP and the sparse rows it got in cycle c - 1 in its sparse-row buffer (they are merged with what the
+ * parts of cycle c find and written back); MC_F_FINAL in the last cycle gives the final rows. */
+int mc_group_set_cycle(mc_group *g, uint32_t cycle);
 /* the member contexts, for mc_get_db_info / mc_get_stats */
 int mc_group_member(mc_group *g, uint32_t i, mc_ctx **out);
 

@@ -17,8 +17,8 @@
 //   malloc          -> mc_group_alloc_batches + mc_group_batch_buffers; the two whole-file result tables
 //                      the host indexes by global read number are plain pinned-size host arrays
 //   readyBatch      -> remembered sizes
-//   queryBatch      -> mc_group_submit  (always returns true: the table is resident, one cycle)
-//   swapDbParts     -> one cycle, then false (reference :775-815 cycles DB parts)
+//   queryBatch      -> mc_group_submit  (MC_F_FOLLOWUP for the re-queries of a cycled database; true in the last cycle)
+//   swapDbParts     -> mc_group_set_cycle: the next cycle's parts, false when all are done (reference :775-815)
 //   waitForBatch    -> mc_group_wait + copy of the batch's rows into the whole-file tables
 //   sync / freeBatchMemory -> mc_group_sync / mc_group_free_batches
 #include "CuClarkDB.cuh"          // the reference's header, unchanged
@@ -36,7 +36,7 @@ namespace {
 
 struct State {
     mc_group *grp = nullptr;
-    int cycles_to_do = 1;
+    int cycles = 1, cycles_to_do = 1, cur = 0;      // database cycles per file (mc_group_info.n_cycles), still to do, loaded now
     bool extended = false;
     size_t row_len = 0, final_len = 0;
     RESULTS *full = nullptr, *final_ = nullptr;
@@ -97,8 +97,9 @@ bool CuClarkDB<HKMERr>::read(const char *_filename, size_t &_fileSize, size_t &_
     mc_group_info info;
     check(mc_group_get_info(s.grp, &info), "mc_group_get_info");
     _fileSize = info.device_bytes_max;
-    _dbParts = 1;                          // everything is resident: one cycle, however many devices
-    s.cycles_to_do = 1;
+    _dbParts = info.n_cycles ? info.n_cycles : 1;      // 1: everything is resident, however many devices
+    s.cycles = s.cycles_to_do = (int)_dbParts;
+    s.cur = 0;
     std::cerr << (m_verbose ? "DB loaded in HBM.\n" : "CuCLARK initialized.\n");
     return true;
 }
@@ -117,7 +118,7 @@ size_t CuClarkDB<HKMERr>::malloc(size_t _numReads, size_t _maxReads, size_t _max
     s.n_reads.assign(m_numBatches, 0);
     s.n_con.assign(m_numBatches, 0);
     check(mc_group_alloc_batches(s.grp, (uint32_t)m_numBatches, _maxReads ? _maxReads : 1, _maxReadsInContainers,
-                                 _isExtended ? 1 : 0), "mc_group_alloc_batches");
+                                 _isExtended || s.cycles > 1 ? 1 : 0), "mc_group_alloc_batches");
     _readsPointer.resize(m_numBatches);
     _readsInCon.resize(m_numBatches);
     for (size_t b = 0; b < m_numBatches; b++)
@@ -156,19 +157,25 @@ bool CuClarkDB<HKMERr>::readyBatch(const size_t _batchId, const size_t _numReads
 }
 
 template <typename HKMERr>
-bool CuClarkDB<HKMERr>::queryBatch(const size_t _batchId, const bool _isExtended, const bool)
+bool CuClarkDB<HKMERr>::queryBatch(const size_t _batchId, const bool _isExtended, const bool _isFollowup)
 {
+    // every batch keeps its own pinned buffers for the whole file (reference malloc): the sparse rows a batch got in the cycle
+    // before are still in its row buffer when it is queried again (followup), and the library merges them in (:932-948)
     State &s = st(this);
+    const bool last = s.cur + 1 == s.cycles;
     check(mc_group_submit(s.grp, (uint32_t)_batchId, s.n_reads[_batchId], s.n_con[_batchId],
-                          MC_F_FINAL | (_isExtended ? MC_F_ROWS : 0)), "mc_group_submit");
-    return true;
+                          (last ? MC_F_FINAL : 0u) | (_isExtended || s.cycles > 1 ? MC_F_ROWS : 0u) | (_isFollowup ? MC_F_FOLLOWUP : 0u)),
+          "mc_group_submit");
+    return last;                           // final results were scheduled (reference :963-979)
 }
 
 template <typename HKMERr>
 bool CuClarkDB<HKMERr>::swapDbParts()
 {
     State &s = st(this);
-    if (s.cycles_to_do == 0) { s.cycles_to_do = 1; return false; }
+    if (s.cycles_to_do == 0) { s.cycles_to_do = s.cycles; return false; }      // reset for a possible next file (reference :778-783)
+    s.cur = s.cycles - s.cycles_to_do;
+    check(mc_group_set_cycle(s.grp, (uint32_t)s.cur), "mc_group_set_cycle");     // nothing to do when those parts are loaded
     s.cycles_to_do--;
     return true;
 }

@@ -63,6 +63,13 @@ struct mc_group {
     // members past S * G (N not a multiple of S) hold nothing.  A batch goes to ONE group.
     uint32_t S = 1, G = 1;
     std::vector<int> last_on_slot;   // [group * 2 + slot]: the batch whose rows the owners last pulled from this slot
+    // a table larger than all members together (the reference's swapDbParts, CuClarkDB.cu:775-815): cycles * N parts, the
+    // members hold those of one cycle; what a change of cycle needs to read the files again
+    uint32_t cycles = 1, cycle = 0;
+    std::string base;
+    int key_bytes = 0, cycle_kind = 0;      // index of the parts (1 minimizer lines, 2 super-k-mer records): one for all cycles
+    uint32_t sampling = 1;
+    double cycle_fill = 0.0;
 };
 
 namespace {
@@ -188,6 +195,39 @@ int mc_group_close(mc_group *g)
     return MC_OK;
 }
 
+namespace {
+// the parts [cycle * N, cycle * N + N) of the cycles * N the table is cut into, one per member
+int load_cycle(mc_group *g, mcint::DbFileStream &F, uint32_t cycle)
+{
+    const uint32_t n = W(g);
+    std::vector<int> saved(n);
+    for (uint32_t m = 0; m < n; m++) { saved[m] = g->ctx[m]->index_mode; if (g->cycle_kind) g->ctx[m]->index_mode = g->cycle_kind; }
+    const int rc = mcint::load_streamed(g->ctx.data(), n, F, g->cycles * n, cycle * n, g->cycle_fill);
+    for (uint32_t m = 0; m < n; m++) g->ctx[m]->index_mode = saved[m];
+    if (rc == MC_OK) {
+        g->cycle = cycle; g->info.cycle = cycle;
+        if (!g->cycle_kind) g->cycle_kind = (int)g->ctx[0]->info.index_kind;
+    }
+    return rc;
+}
+} // namespace
+
+int mc_group_set_cycle(mc_group *g, uint32_t cycle)
+{
+    if (!g) return fail(MC_EINVAL, "group is NULL");
+    if (!g->loaded) return fail(MC_ESTATE, "mc_group_set_cycle before a database was loaded");
+    if (cycle >= g->cycles) return fail(MC_EINVAL, "no such cycle");
+    if (cycle == g->cycle) return MC_OK;
+    int rc = mc_group_sync(g);
+    if (rc) return rc;
+    mcint::DbFileStream F;
+    if ((rc = F.open(g->base.c_str(), g->key_bytes, g->sampling, g->htsize, 0, g->htsize)) != MC_OK) return rc;
+    g->loaded = false;
+    if ((rc = load_cycle(g, F, cycle)) != MC_OK) return rc;
+    g->loaded = true;
+    return MC_OK;
+}
+
 int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t sampling, int mode)
 {
     if (!g || !base) return fail(MC_EINVAL, "group/base is NULL");
@@ -300,6 +340,29 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
             if (rc == MC_OK) g->ctx[m]->info.index_fallback = 1u;
         }
     }
+    uint32_t forced_cycles = 0;
+    if (const char *e = getenv("MC_GROUP_CYCLES")) { const long v = atol(e); if (v >= 2 && v <= 64) forced_cycles = (uint32_t)v; }
+    g->cycles = 1; g->cycle = 0; g->cycle_kind = 0; g->cycle_fill = 0.0;
+    if ((rc == MC_ENOMEM || (forced_cycles && rc == MC_OK)) && mz && by_lines && n <= mc::MERGE_MAX_SRCS - 1) {
+        // Larger than all members together (the reference's swapDbParts, CuClarkDB.cu:775-815): C * N parts, N at a time.  The
+        // caller classifies every batch once per cycle and the rows add up (mc_group_set_cycle, MC_F_FOLLOWUP).
+        const uint32_t s_all = mcint::min_parts(F.n_keys_kept, 4096, free_min, MC_GROUP_MAX_FILL);
+        uint32_t C = forced_cycles ? forced_cycles : std::max<uint32_t>(2, s_all ? (s_all + n - 1) / n : 2);
+        for (;; C++) {
+            g->cycles = C; g->cycle_kind = 0;
+            g->cycle_fill = mcint::choose_fill(F.n_keys_kept, C * n, free_min);
+            rc = load_cycle(g, F, 0);
+            if (rc != MC_ENOMEM || forced_cycles || C >= 64) break;
+            fprintf(stderr, "libmcclark: %s; %u cycles\n", mc_last_error(), C + 1);
+        }
+        if (rc == MC_OK) {
+            fprintf(stderr, "libmcclark: the database does not fit the %u device(s) together: %u parts, %u at a time (%u cycles per file)\n", n, C * n, n, C);
+            mode = MC_GROUP_SHARDS; shard_kind = 1; g->S = n; g->G = 1;
+            for (mc_ctx *c : g->ctx) c->info.index_fallback = 0u;
+        } else {
+            g->cycles = 1;
+        }
+    }
     if (rc == MC_ENOMEM)
         return fail(MC_ENOMEM, std::string("the database does not fit the ") + std::to_string(n) + " device(s) of the group (" +
                                    mc_last_error() + "); use more devices (-d)");
@@ -311,6 +374,8 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
     g->info.bytes_free_min = free_min;
     g->info.device_bytes_max = 0;
     g->info.n_shards = g->S; g->info.n_groups = g->G;
+    g->info.n_cycles = g->cycles; g->info.cycle = g->cycle;
+    g->base = base; g->key_bytes = key_bytes; g->sampling = sampling;
     for (mc_ctx *c : g->ctx) if (c->db_loaded) g->info.device_bytes_max = std::max<uint64_t>(g->info.device_bytes_max, c->info.device_bytes);
     g->last_on_slot.assign((size_t)g->G * 2, -1);
     g->loaded = true;
@@ -378,7 +443,7 @@ int mc_group_alloc_batches(mc_group *g, uint32_t n_batches, uint64_t max_reads, 
     g->d_slab.assign(n, nullptr);
     const size_t d_ptr = up((max_reads + 1) * 4), d_con = up(max_con * 2);
     const size_t d_rows = shards ? up(max_reads * row_len * 2) : (g->want_rows ? up(max_reads * row_len * 2) : 0);
-    const size_t d_recv = shards ? up((size_t)(g->S > 1 ? g->S - 1 : 1) * g->per * row_len * 2) : 0;
+    const size_t d_recv = shards ? up((size_t)(g->cycles > 1 ? g->S : (g->S > 1 ? g->S - 1 : 1)) * g->per * row_len * 2) : 0;
     const size_t d_fin = up((shards ? g->per : max_reads) * MC_FINAL_ROW * 2);
     const size_t d_mrg = shards && g->want_rows ? up(g->per * row_len * 2) : 0;
     const size_t per_slot = d_ptr + d_con + d_rows + d_recv + d_fin + d_mrg;
@@ -425,6 +490,8 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
     if (n_reads > g->max_reads || n_con > g->max_con) return fail(MC_EINVAL, "batch larger than allocated");
     if (!(flags & (MC_F_FINAL | MC_F_ROWS))) return fail(MC_EINVAL, "flags select no output");
     if ((flags & MC_F_ROWS) && !g->want_rows) return fail(MC_ESTATE, "sparse rows were not allocated");
+    if ((flags & MC_F_FOLLOWUP) && (g->cycles < 2 || !g->want_rows))
+        return fail(MC_ESTATE, "MC_F_FOLLOWUP needs a database that is loaded in cycles, and batches with sparse rows");
     GBatch &b = g->batches[batch];
     if (n_reads && b.h_ptr[n_reads] != n_con) return fail(MC_EINVAL, "reads_ptr[n_reads] != n_containers");
     const uint32_t n = W(g);
@@ -492,7 +559,13 @@ int mc_group_submit(mc_group *g, uint32_t batch, uint64_t n_reads, uint64_t n_co
                 srcs[i] = dst;
                 r++;
             }
-            rc = mcint::launch_merge_result(c, srcs, S, cnt, (flags & MC_F_ROWS) ? s.d_merged : nullptr,
+            uint32_t n_srcs = S;
+            if (flags & MC_F_FOLLOWUP) {      // the rows the earlier cycles gave these reads: one more source (CuClarkDB.cu:932-948)
+                uint16_t *dst = s.d_recv + (size_t)r * g->per * row_len;
+                HIPCHK(hipMemcpyAsync(dst, b.h_rows + lo * row_len, cnt * row_len * 2, hipMemcpyHostToDevice, st));
+                srcs[n_srcs++] = dst;
+            }
+            rc = mcint::launch_merge_result(c, srcs, n_srcs, cnt, (flags & MC_F_ROWS) ? s.d_merged : nullptr,
                                             (flags & MC_F_FINAL) ? s.d_final : nullptr, st);
             if (rc) return rc;
             if (flags & MC_F_FINAL)

@@ -145,6 +145,9 @@ struct Classifier {
     mc_group *grp = nullptr;
     bool paired = false;
     bool text_path = false;          // every member of the group holds the whole table: FASTQ batches may go to the card as text
+    uint32_t db_cycles = 1;          // > 1: the table is larger than all devices together; every file is classified once per cycle
+    // one pass of a file over the parts of one database cycle (reference: the swapDbParts loop, src/CuCLARK_hh.hh:1765-1772)
+    struct Cycle { uint32_t i, n; std::vector<uint16_t> *rows; };      // rows: the sparse rows of every read of the file, kept between the passes
     size_t n_objects = 0;
 
     void open_devices()
@@ -196,6 +199,7 @@ struct Classifier {
         mc_group_info gi;
         mc_group_get_info(grp, &gi);
         text_path = gi.mode == MC_GROUP_REPLICAS;
+        db_cycles = gi.n_cycles ? gi.n_cycles : 1;
         if (opt.verbose) {
             mc_ctx *c0 = nullptr;
             mc_db_info info;
@@ -205,6 +209,7 @@ struct Classifier {
                       << (gi.mode == MC_GROUP_SHARDS ? (gi.shard_kind == 1 ? "shards by minimizer line range" : "shards by bucket range")
                                                      : "replicas");
             if (gi.mode == MC_GROUP_SHARDS) std::cerr << ": " << gi.n_shards << " parts x " << gi.n_groups << " groups";
+            if (gi.n_cycles > 1) std::cerr << ", " << gi.n_cycles << " database cycles per file";
             std::cerr << ", peer access " << (gi.peer_access ? "yes" : "no") << ")\n";
             std::cerr << "Total DB size in HBM:\t" << gi.device_bytes_max / 1000000 / 1000.0 << " GB per device (" << gi.n_keys
                       << " k-mers, " << (info.index_kind == MC_INDEX_MINIMIZER ? "minimizer index" : info.index_kind == MC_INDEX_SUPERKMER ? "super-k-mer index" : "bucket-line table")
@@ -239,7 +244,7 @@ struct Classifier {
         size_t stream_min = 8u << 20;
         if (const char *e = getenv("MC_STREAM_MIN_BYTES")) stream_min = (size_t)std::strtoull(e, nullptr, 10);
         if (a.size() >= stream_min && b.size() >= stream_min && !opt.dump && a.data()[0] == '@' && b.data()[0] == '@' &&
-            !getenv("MC_JOIN_MATES")) {
+            !getenv("MC_JOIN_MATES") && db_cycles == 1) {
             const Mates m{b.data(), b.size()};
             if (classify_image(a.data(), a.size(), result, true, &m)) { done_line(t0, result); return; }
         }
@@ -298,15 +303,32 @@ struct Classifier {
         size_t stream_min = 8u << 20;
         if (const char *e = getenv("MC_STREAM_MIN_BYTES")) stream_min = (size_t)std::strtoull(e, nullptr, 10);
         bool done = false;
+        if (db_cycles > 1) {
+            // The table does not fit the devices together: the file is classified once per database cycle -- the same batches every
+            // time (the plan that indexes the file as a whole), their sparse rows kept here in between and merged on the card with
+            // what the next cycle's parts find; the last pass writes the CSV.
+            std::vector<uint16_t> rows;
+            for (uint32_t c = 0; c < db_cycles; c++) {
+                mc_check(mc_group_set_cycle(grp, c), "mc_group_set_cycle");
+                Cycle cy{c, db_cycles, &rows};
+                classify_image(map, nb, result, false, nullptr, &cy);
+            }
+            mc_check(mc_group_set_cycle(grp, 0), "mc_group_set_cycle");         // ready for the next file
+            done_line(t0, result);
+            return;
+        }
         if (nb >= stream_min && !opt.dump && (map[0] == '>' || map[0] == '@')) done = classify_image(map, nb, result, true);
         if (!done) classify_image(map, nb, result, false);
         done_line(t0, result);
     }
 
     // false: the streamed attempt met a byte range its buffers do not take (nothing of the result is kept)
-    bool classify_image(const uint8_t *map, size_t nb, const char *result, const bool streamed, const Mates *mates = nullptr)
+    bool classify_image(const uint8_t *map, size_t nb, const char *result, const bool streamed, const Mates *mates = nullptr,
+                        const Cycle *cyc = nullptr)
     {
         const std::string csv = std::string(result) + ".csv";
+        const bool last_cycle = !cyc || cyc->i + 1 == cyc->n;
+        const bool want_rows = opt.ext || cyc;
         FILE *fout = std::fopen(csv.c_str(), "w");
         if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return true; }
 
@@ -345,7 +367,7 @@ struct Classifier {
                 dev_ingest = card_wanted && guess_con <= 0xFFFFFFFFull;
                 if (guess_con <= 0xFFFFFFFFull && !dev_ingest)
                     early_alloc = std::thread([&]() {
-                        early_rc = mc_group_alloc_batches(grp, (uint32_t)guess_nbuf, guess_reads, guess_con, opt.ext ? 1 : 0);
+                        early_rc = mc_group_alloc_batches(grp, (uint32_t)guess_nbuf, guess_reads, guess_con, want_rows ? 1 : 0);
                         if (early_rc != MC_OK) early_err = mc_last_error();
                     });
             }
@@ -432,11 +454,13 @@ struct Classifier {
                 if (!have_buffers && early_rc == MC_OK) mc_group_free_batches(grp);          // the guess was too small
             }
             if (!have_buffers)
-                mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, opt.ext ? 1 : 0), "mc_group_alloc_batches");
+                mc_check(mc_group_alloc_batches(grp, (uint32_t)nbuf, max_reads, max_con, want_rows ? 1 : 0), "mc_group_alloc_batches");
             ts2 = now();
         }
 
-        const uint32_t flags = MC_F_FINAL | (opt.ext ? MC_F_ROWS : 0);
+        const uint32_t flags = (last_cycle ? MC_F_FINAL : 0u) | (want_rows ? MC_F_ROWS : 0u) | (cyc && cyc->i ? MC_F_FOLLOWUP : 0u);
+        const size_t rows_len = 2 * (size_t)MAXHITS + 2;
+        if (cyc && cyc->i == 0) cyc->rows->assign(R.size() * rows_len, 0);
 
         // One pool of worker threads runs three kinds of tasks: INDEX (streamed plan: the records of a byte range),
         // PACK (2-bit pack a batch into its pinned buffers, then submit it: H2D, kernel, D2H are asynchronous) and
@@ -501,6 +525,11 @@ struct Classifier {
                 X.ncon = mates ? pack_mates(X.text, X.own, X.text2, X.own2, X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text),
                                             (size_t)(mates->b + mates->nb - X.text2))
                                : pack_reads(X.text, *X.R, X.r0, X.r0 + X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text));
+                if (cyc && cyc->i) {
+                    uint16_t *rows_in = nullptr;
+                    mc_check(mc_group_batch_buffers(grp, buf, nullptr, nullptr, nullptr, &rows_in), "mc_group_batch_buffers");
+                    std::memcpy(rows_in, cyc->rows->data() + X.r0 * rows_len, X.n * rows_len * 2);
+                }
                 std::lock_guard<std::mutex> lk(submit_mu);
                 mc_check(mc_group_submit(grp, buf, X.n, X.ncon, flags), "mc_group_submit");
             }
@@ -522,6 +551,21 @@ struct Classifier {
             for (size_t b = 0; b < nbuf; b++) enqueue_pack(b);
         }
 
+        if (cyc && !last_cycle) {
+            for (size_t b = 0; b < nbatch; b++) {
+                { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return B[b].submitted; }); }
+                uint16_t *rows_out = nullptr;
+                mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
+                mc_check(mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, nullptr, &rows_out), "mc_group_batch_buffers");
+                std::memcpy(cyc->rows->data() + B[b].r0 * rows_len, rows_out, B[b].n * rows_len * 2);
+                if (b + nbuf < nbatch) enqueue_pack(b + nbuf);
+            }
+            pool.finish();
+            std::fclose(fout);
+            if (opt.verbose) std::cerr << "database cycle " << cyc->i + 1 << " of " << cyc->n << ": " << now() - ts0 << " s\n";
+            mc_group_free_batches(grp);
+            return true;
+        }
         // header (reference :1951-1967)
         std::string head = "Object_ID";
         if (opt.ext) for (size_t t = 1; t < T.names.size(); t++) { head += ","; head += T.names[t]; }

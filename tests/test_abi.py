@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.library_path())
     for name in _declared_symbols() + _declared_symbols("mc_group.h"):
         assert hasattr(lib, name), name
-    assert len(_declared_symbols("mc_group.h")) == 15          # (round 4: + the four mc_group_text_* entry points)
-    assert _lib.load_library().mc_api_version() == 3
+    assert len(_declared_symbols("mc_group.h")) == 16          # (round 4: + the four mc_group_text_* entry points, + mc_group_set_cycle)
+    assert _lib.load_library().mc_api_version() == 4
 
 
 def test_builder_symbols_exported():

@@ -718,6 +718,11 @@ def test_fast_g_format_matches_printf(tmp_path):
     ("0,0,0", {"MC_GROUP_MODE": "shards", "MC_INDEX": "auto"}, "shards by minimizer line range"),
     ("0", {"MC_MZ_ALLOC_LIMIT": "65536"}, "replicas"),
     ("0,0", {"MC_MZ_ALLOC_LIMIT": "65536"}, "shards by bucket range"),
+    # a table larger than all devices together (forced: MC_GROUP_CYCLES): C x N parts, N at a time, every batch classified once
+    # per cycle and the rows of the cycles merged on the card (the reference's swapDbParts loop, CuClarkDB.cu:775-815)
+    ("0", {"MC_GROUP_CYCLES": "2"}, "shards by minimizer line range: 1 parts x 1 groups, 2 database cycles per file"),
+    ("0,0", {"MC_GROUP_CYCLES": "3"}, "shards by minimizer line range: 2 parts x 1 groups, 3 database cycles per file"),
+    ("0,0", {"MC_GROUP_CYCLES": "2", "MC_INDEX": "skm"}, "shards by minimizer line range: 2 parts x 1 groups, 2 database cycles per file"),
 ])
 @pytest.mark.parametrize("extended", [False, True])
 def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members, env, expect, extended):
@@ -768,6 +773,10 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
     assert ("Devices: %d (%s" % (len(members.split(",")), expect)) in many.stderr, many.stderr
     if env.get("MC_INDEX") == "skm":          # ("auto" may take either: this toy table holds a few hundred k-mers)
         assert "super-k-mer index" in many.stderr, many.stderr
+    if "MC_GROUP_CYCLES" in env:
+        c, n = int(env["MC_GROUP_CYCLES"]), len(members.split(","))
+        assert ("%d parts, %d at a time (%d cycles per file)" % (c * n, n, c)) in many.stderr, many.stderr
+        assert ("database cycle %d of %d" % (c - 1, c)) in many.stderr, many.stderr
     if "MC_MZ_ALLOC_LIMIT" in env:
         assert "falling back to the bucket-line table" in many.stderr and "[fallback: the minimizer index did not fit]" in many.stderr, many.stderr
     if "replicas" not in expect and "parts x" not in expect:
@@ -778,6 +787,41 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
     want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, extended=extended)
     assert b == want
     assert sum(ln.split(",")[-3] != "NA" for ln in b.split("\n")[1:-1]) > 1500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mates", "fasta"])
+def test_database_cycles_with_mates_and_fasta(tmp_path, kind):
+    """The cycled database (see above) with the other inputs: mates of two FASTQ files -- joined first, the file is classified
+    once per cycle from the joined text -- and a multi-line FASTA file; byte-identical to the run on the resident table."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta
+    _build()
+    k = 27
+    genomes = synth.toy_genomes(5, 5000, seed=67, shared=300)
+    labels = ["A", "B", "C", "D", "E"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
+    (tmp_path / "db").mkdir()
+    names, seqs = mixed_fasta(genomes, k, seed=29, n=3000)
+    if kind == "mates":
+        nm = [n.split(b" ")[0] for n in names]
+        (tmp_path / "r_1.fq").write_bytes(synth.fastq_text([n + b"/1" for n in nm], [s[:90].replace(b"\n", b"") for s in seqs]))
+        (tmp_path / "r_2.fq").write_bytes(synth.fastq_text([n + b"/2" for n in nm], [s[50:150] for s in seqs]))
+        inp = ["-P", str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")]
+    else:
+        (tmp_path / "reads.fa").write_bytes(synth.fasta_text(names, seqs, width=60))
+        inp = ["-O", str(tmp_path / "reads.fa")]
+    common = ["-T", targets, "-D", str(tmp_path / "db")] + inp + ["-n", "4", "-b", "7", "--verbose"]
+    out = {}
+    for tag, env in (("resident", {}), ("cycled", {"MC_GROUP_CYCLES": "3", "MC_STREAM_MIN_BYTES": "1000"})):
+        r = subprocess.run([os.path.join(BIN, "cuCLARK-l")] + common + ["-R", str(tmp_path / tag), "-d", "1"],
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        assert ("3 database cycles per file" in r.stderr) == (tag == "cycled"), r.stderr
+        out[tag] = open(str(tmp_path / (tag + ".csv"))).read()
+    assert out["cycled"] == out["resident"] and out["cycled"].count("\n") == 3001
+    assert sum(ln.split(",")[-3] != "NA" for ln in out["cycled"].split("\n")[1:-1]) > 1000
 
 
 @pytest.mark.gpu
