@@ -313,7 +313,7 @@ int mc_group_load_db(mc_group *g, const char *base, int key_bytes, uint32_t samp
         g->S = mode == MC_GROUP_SHARDS ? S : 1; g->G = mode == MC_GROUP_SHARDS ? G : n;
         break;
     }
-    if (rc == MC_ENOMEM && mz) {
+    if (rc == MC_ENOMEM && mz && !getenv("MC_GROUP_NO_LINES_FALLBACK")) {      // (the variable: how the tests get past this to the database cycles)
         // Last resort, whatever the mode asked for: the bucket-line table (about 3x slower to query, a third of the
         // memory at dense fills) -- whole on every member when it fits one, else cut by the reference's bucket ranges
         // (CuClarkDB.cu:552-559).  Said aloud; mc_db_info of the members carries index_fallback = 1.

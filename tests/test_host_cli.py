@@ -723,6 +723,9 @@ def test_fast_g_format_matches_printf(tmp_path):
     ("0", {"MC_GROUP_CYCLES": "2"}, "shards by minimizer line range: 1 parts x 1 groups, 2 database cycles per file"),
     ("0,0", {"MC_GROUP_CYCLES": "3"}, "shards by minimizer line range: 2 parts x 1 groups, 3 database cycles per file"),
     ("0,0", {"MC_GROUP_CYCLES": "2", "MC_INDEX": "skm"}, "shards by minimizer line range: 2 parts x 1 groups, 2 database cycles per file"),
+    # not forced: the minimizer lines "do not fit" the two members in any cut and the bucket-line table is kept out of the way --
+    # the loader adds cycles until a part fits
+    ("0,0", {"MC_MZ_ALLOC_LIMIT": "300000", "MC_GROUP_NO_LINES_FALLBACK": "1", "MC_INDEX": "minimizer"}, "shards by minimizer line range: 2 parts x 1 groups, "),
 ])
 @pytest.mark.parametrize("extended", [False, True])
 def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members, env, expect, extended):
@@ -777,7 +780,9 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
         c, n = int(env["MC_GROUP_CYCLES"]), len(members.split(","))
         assert ("%d parts, %d at a time (%d cycles per file)" % (c * n, n, c)) in many.stderr, many.stderr
         assert ("database cycle %d of %d" % (c - 1, c)) in many.stderr, many.stderr
-    if "MC_MZ_ALLOC_LIMIT" in env:
+    if "MC_GROUP_NO_LINES_FALLBACK" in env:
+        assert "database cycles per file" in many.stderr and "at a time (" in many.stderr, many.stderr
+    elif "MC_MZ_ALLOC_LIMIT" in env:
         assert "falling back to the bucket-line table" in many.stderr and "[fallback: the minimizer index did not fit]" in many.stderr, many.stderr
     if "replicas" not in expect and "parts x" not in expect:
         assert ("%d parts x 1 groups" % len(members.split(","))) in many.stderr, many.stderr
