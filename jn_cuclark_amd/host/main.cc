@@ -562,7 +562,7 @@ struct Classifier {
             }
             pool.finish();
             std::fclose(fout);
-            if (opt.verbose) std::cerr << "database cycle " << cyc->i + 1 << " of " << cyc->n << ": " << now() - ts0 << " s\n";
+            if (opt.verbose) std::cerr << "timing: database cycle " << cyc->i + 1 << " of " << cyc->n << ": " << now() - ts0 << " s\n";
             mc_group_free_batches(grp);
             return true;
         }
