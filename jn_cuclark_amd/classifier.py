@@ -136,8 +136,8 @@ class CuClarkDB:
         return {f: getattr(st, f) for f, _ in McStats._fields_}
 
     def swapDbParts(self):
-        """The whole shard stays resident in HBM, so there is exactly one cycle
-        (reference :775-815 cycles parts through a small device)."""
+        """A single context keeps its table (or its part of one) resident in HBM: exactly one cycle here.  A table larger than all
+        devices together is cycled by the group (include/mc_group.h: mc_group_set_cycle, MC_F_FOLLOWUP; reference :775-815)."""
         if self._cycles_to_do == 0:
             self._cycles_to_do = 1
             return False
