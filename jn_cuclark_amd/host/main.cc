@@ -145,7 +145,7 @@ struct Classifier {
     mc_group *grp = nullptr;
     bool paired = false;
     bool text_path = false;          // every member of the group holds the whole table: FASTQ batches may go to the card as text
-    uint32_t db_cycles = 1;          // > 1: the table is larger than all devices together; every file is classified once per cycle
+    uint32_t db_cycles = 1, db_cycle = 0;      // > 1: the table is larger than all devices together; every file is classified once per cycle (db_cycle: the parts loaded now)
     // one pass of a file over the parts of one database cycle (reference: the swapDbParts loop, src/CuCLARK_hh.hh:1765-1772)
     struct Cycle { uint32_t i, n; std::vector<uint16_t> *rows; };      // rows: the sparse rows of every read of the file, kept between the passes
     size_t n_objects = 0;
@@ -200,6 +200,7 @@ struct Classifier {
         mc_group_get_info(grp, &gi);
         text_path = gi.mode == MC_GROUP_REPLICAS;
         db_cycles = gi.n_cycles ? gi.n_cycles : 1;
+        db_cycle = gi.cycle;
         if (opt.verbose) {
             mc_ctx *c0 = nullptr;
             mc_db_info info;
@@ -307,13 +308,15 @@ struct Classifier {
             // The table does not fit the devices together: the file is classified once per database cycle -- the same batches every
             // time (the plan that indexes the file as a whole), their sparse rows kept here in between and merged on the card with
             // what the next cycle's parts find; the last pass writes the CSV.
+            // The passes add up in any order: a file starts with the parts the file before it ended with (C - 1 loads per file, where
+            // the reference goes back to its first parts for every file: C).
             std::vector<uint16_t> rows;
-            for (uint32_t c = 0; c < db_cycles; c++) {
-                mc_check(mc_group_set_cycle(grp, c), "mc_group_set_cycle");
-                Cycle cy{c, db_cycles, &rows};
+            for (uint32_t i = 0; i < db_cycles; i++) {
+                if (i) db_cycle = (db_cycle + 1) % db_cycles;
+                mc_check(mc_group_set_cycle(grp, db_cycle), "mc_group_set_cycle");
+                Cycle cy{i, db_cycles, &rows};
                 classify_image(map, nb, result, false, nullptr, &cy);
             }
-            mc_check(mc_group_set_cycle(grp, 0), "mc_group_set_cycle");         // ready for the next file
             done_line(t0, result);
             return;
         }

@@ -796,10 +796,11 @@ def test_several_devices_produce_the_single_device_csv(oracle, tmp_path, members
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["mates", "fasta"])
+@pytest.mark.parametrize("kind", ["mates", "fasta", "two_files"])
 def test_database_cycles_with_mates_and_fasta(tmp_path, kind):
     """The cycled database (see above) with the other inputs: mates of two FASTQ files -- joined first, the file is classified
-    once per cycle from the joined text -- and a multi-line FASTA file; byte-identical to the run on the resident table."""
+    once per cycle from the joined text --, a multi-line FASTA file, and a list of two files (the second starts with the parts the
+    first ended with); byte-identical to the run on the resident table."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import mixed_fasta
@@ -815,18 +816,30 @@ def test_database_cycles_with_mates_and_fasta(tmp_path, kind):
         (tmp_path / "r_1.fq").write_bytes(synth.fastq_text([n + b"/1" for n in nm], [s[:90].replace(b"\n", b"") for s in seqs]))
         (tmp_path / "r_2.fq").write_bytes(synth.fastq_text([n + b"/2" for n in nm], [s[50:150] for s in seqs]))
         inp = ["-P", str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")]
+    elif kind == "two_files":
+        (tmp_path / "a.fq").write_bytes(synth.fastq_text(names[:1700], seqs[:1700]))
+        (tmp_path / "b.fa").write_bytes(synth.fasta_text(names[1700:], seqs[1700:], width=60))
+        (tmp_path / "objects.txt").write_text("%s\n%s\n" % (tmp_path / "a.fq", tmp_path / "b.fa"))
+        inp = ["-O", str(tmp_path / "objects.txt")]
     else:
         (tmp_path / "reads.fa").write_bytes(synth.fasta_text(names, seqs, width=60))
         inp = ["-O", str(tmp_path / "reads.fa")]
     common = ["-T", targets, "-D", str(tmp_path / "db")] + inp + ["-n", "4", "-b", "7", "--verbose"]
     out = {}
     for tag, env in (("resident", {}), ("cycled", {"MC_GROUP_CYCLES": "3", "MC_STREAM_MIN_BYTES": "1000"})):
-        r = subprocess.run([os.path.join(BIN, "cuCLARK-l")] + common + ["-R", str(tmp_path / tag), "-d", "1"],
+        res = str(tmp_path / tag)
+        if kind == "two_files":          # a list of result names next to the list of inputs (reference run(), src/CuCLARK_hh.hh:383-506)
+            (tmp_path / (tag + "_results.txt")).write_text("%s_a\n%s_b\n" % (res, res))
+            res = str(tmp_path / (tag + "_results.txt"))
+        r = subprocess.run([os.path.join(BIN, "cuCLARK-l")] + common + ["-R", res, "-d", "1"],
                            capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr
         assert ("3 database cycles per file" in r.stderr) == (tag == "cycled"), r.stderr
-        out[tag] = open(str(tmp_path / (tag + ".csv"))).read()
-    assert out["cycled"] == out["resident"] and out["cycled"].count("\n") == 3001
+        if kind == "two_files":
+            out[tag] = open(str(tmp_path / (tag + "_a.csv"))).read() + open(str(tmp_path / (tag + "_b.csv"))).read()
+        else:
+            out[tag] = open(str(tmp_path / (tag + ".csv"))).read()
+    assert out["cycled"] == out["resident"] and out["cycled"].count("\n") == (3002 if kind == "two_files" else 3001)
     assert sum(ln.split(",")[-3] != "NA" for ln in out["cycled"].split("\n")[1:-1]) > 1000
 
 
