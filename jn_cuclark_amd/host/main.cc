@@ -24,6 +24,7 @@
 #include "reads.hpp"
 #include "input.hpp"
 #include "pairs.hpp"
+#include "gzstream.hpp"
 #include "format.hpp"
 
 #include <fcntl.h>
@@ -148,6 +149,13 @@ struct Classifier {
     uint32_t db_cycles = 1, db_cycle = 0;      // > 1: the table is larger than all devices together; every file is classified once per cycle (db_cycle: the parts loaded now)
     // one pass of a file over the parts of one database cycle (reference: the swapDbParts loop, src/CuCLARK_hh.hh:1765-1772)
     struct Cycle { uint32_t i, n; std::vector<uint16_t> *rows; };      // rows: the sparse rows of every read of the file, kept between the passes
+    // a gzip file that is classified segment by segment (gzstream.hpp): what one segment's pass leaves for the next
+    struct Seg {
+        bool first = true, last = false;
+        uint64_t csv_bytes = 0;            // where the next segment's lines go
+        size_t objects = 0;
+        long nz_min = 0, nz_max = 0, nz_sum = 0;
+    };
     size_t n_objects = 0;
 
     void open_devices()
@@ -226,10 +234,58 @@ struct Classifier {
     void run_simple(const char *objects, const char *result)
     {
         std::cerr << "Classifying: " << objects << "\n";
-        InputImage img;                 // mmap, or inflated in memory when the file is gzip
+        if (db_cycles == 1 && !opt.dump && !getenv("MC_GZ_WHOLE") && GzSegments::is_gzip(objects)) { run_gz_segments(objects, result); return; }
+        InputImage img;                 // mmap, or inflated in memory when the file is gzip (database cycles, --dump-batches)
         std::string ierr;
         if (!img.load(objects, ierr)) { std::cerr << ierr << std::endl; return; }
         run_image(img.data(), img.size(), result);
+    }
+
+    // A gzip file goes through in segments of whole records (MC_GZ_SEGMENT_MB of text, 256 by default): a thread inflates the
+    // next ones while this one is classified -- the streamed plan per segment, the whole-segment plan when that gives up -- and
+    // every segment's lines are written behind the lines of the one before.  Three segments of text are in memory at a time
+    // instead of the whole file; the first lines are out after one segment's worth of inflating; bgzip's blocks are inflated
+    // by all -n threads at once, any other gzip file by one.  (The reference's wrapper
+    // copies the file and gunzips the copy before the classifier starts: scripts/classify_metagenome.sh:118-137.)
+    void run_gz_segments(const char *objects, const char *result)
+    {
+        size_t seg_bytes = (size_t)256 << 20;
+        if (const char *e = getenv("MC_GZ_SEGMENT_MB")) { const long v = atol(e); if (v >= 1 && v <= 65536) seg_bytes = (size_t)v << 20; }
+        if (const char *e = getenv("MC_GZ_SEGMENT_BYTES")) { const long long v = atoll(e); if (v >= 64) seg_bytes = (size_t)v; }       // (tests)
+        GzSegments G;
+        std::string err;
+        if (!G.open(objects, seg_bytes, err, (int)opt.cpu)) { std::cerr << err << std::endl; return; }       // (-n threads inflate a BGZF file)
+        struct timeval t0;
+        gettimeofday(&t0, nullptr);
+        size_t stream_min = 8u << 20;
+        if (const char *e = getenv("MC_STREAM_MIN_BYTES")) stream_min = (size_t)std::strtoull(e, nullptr, 10);
+        Seg st;
+        st.nz_min = (long)T.names.size() - 1;
+        GzSegments::Segment s;
+        size_t n_seg = 0;
+        while (G.next(s, err)) {
+            if (s.size == 0 && st.first) { std::cerr << "Failed to open " << objects << std::endl; return; }       // (as an empty file)
+            st.last = s.last;
+            bool done = false;
+            if (s.size >= stream_min && (s.data[0] == '>' || s.data[0] == '@')) done = classify_image(s.data, s.size, result, true, nullptr, nullptr, &st);
+            if (!done) classify_image(s.data, s.size, result, false, nullptr, nullptr, &st);
+            st.first = false;
+            n_seg++;
+        }
+        if (!err.empty()) {
+            // the text stops being gzip somewhere: nothing is classified when the first segment already fails (as the whole-file
+            // path, which inflates first); later, the lines written so far stay and the run ends with an error
+            std::cerr << err << std::endl;
+            if (n_seg == 0) return;
+            std::cerr << "ERROR: " << objects << ": the results file holds the first " << st.objects << " reads only." << std::endl;
+            std::exit(1);
+        }
+        if (opt.verbose) {
+            std::cerr << "gzip input classified in " << n_seg << " segment(s) of at most " << G.largest_segment() << " bytes of text";
+            if (G.bgzf()) std::cerr << " (BGZF: " << G.bgzf_blocks() << " blocks inflated on " << opt.cpu << " threads)";
+            std::cerr << "\n";
+        }
+        done_line(t0, result);
     }
 
     // paired FASTQ mates (the reference goes through a temporary FASTA file): classified straight from the two files
@@ -326,13 +382,16 @@ struct Classifier {
     }
 
     // false: the streamed attempt met a byte range its buffers do not take (nothing of the result is kept)
+    // seg: this text is one segment of a file (run_gz_segments): lines go behind those of the segments before, the header
+    // with the first, the closing messages with the last
     bool classify_image(const uint8_t *map, size_t nb, const char *result, const bool streamed, const Mates *mates = nullptr,
-                        const Cycle *cyc = nullptr)
+                        const Cycle *cyc = nullptr, Seg *seg = nullptr)
     {
         const std::string csv = std::string(result) + ".csv";
         const bool last_cycle = !cyc || cyc->i + 1 == cyc->n;
         const bool want_rows = opt.ext || cyc;
-        FILE *fout = std::fopen(csv.c_str(), "w");
+        const bool opens_csv = !seg || seg->first, closes_csv = !seg || seg->last;
+        FILE *fout = std::fopen(csv.c_str(), opens_csv ? "w" : "r+");
         if (!fout) { std::cerr << "Failed to create/open file result: " << csv << std::endl; return true; }
 
         ReadIndex R;
@@ -573,14 +632,15 @@ struct Classifier {
         std::string head = "Object_ID";
         if (opt.ext) for (size_t t = 1; t < T.names.size(); t++) { head += ","; head += T.names[t]; }
         head += ",Gamma,Assignment,Score,Confidence\n";
-        std::fwrite(head.data(), 1, head.size(), fout);
+        if (opens_csv) std::fwrite(head.data(), 1, head.size(), fout);
         std::fflush(fout);
         const int fd = fileno(fout);
-        uint64_t file_off = head.size();             // slices are written with pwrite by the pool, in parallel
-        std::cerr << (opt.ext ? "Writing extended results... " : "Writing results... ") << std::endl;
+        uint64_t file_off = opens_csv ? head.size() : seg->csv_bytes;             // slices are written with pwrite by the pool, in parallel
+        if (opens_csv) std::cerr << (opt.ext ? "Writing extended results... " : "Writing results... ") << std::endl;
 
         const size_t row_len = 2 * (size_t)MAXHITS + 2;
         long nz_min = (long)T.names.size() - 1, nz_max = 0, nz_sum = 0;
+        if (seg && !seg->first) { nz_min = seg->nz_min; nz_max = seg->nz_max; nz_sum = seg->nz_sum; }
         // a batch's lines are formatted in parallel slices (same printf conversions as the
         // reference, :2115-2118) and written in read order
         const int nfmt = (int)std::max<size_t>(1, opt.cpu);
@@ -794,7 +854,8 @@ struct Classifier {
                                                    : "streamed ingest given up (a range of the file exceeds the guessed buffers); indexing the whole file\n");
             return false;
         }
-        n_objects = n_done;
+        n_objects = (seg ? seg->objects : 0) + n_done;
+        if (seg) { seg->objects = n_objects; seg->csv_bytes = file_off; seg->nz_min = nz_min; seg->nz_max = nz_max; seg->nz_sum = nz_sum; }
         if (opt.dump) {
             FILE *dump = std::fopen(opt.dump, "wb");
             for (size_t b = 0; dump && b < nbatch; b++) {           // (nbuf == nbatch when dumping)
@@ -818,8 +879,8 @@ struct Classifier {
                 std::cerr << "timing: index " << ts1 - ts0 << " s, alloc " << ts2 - ts1 << " s, pack+submit | wait+format+write (overlapped) "
                           << now() - ts2 << " s\n";
         }
-        std::cerr << "Done." << std::endl;
-        if (opt.ext && n_objects)
+        if (closes_csv) std::cerr << "Done." << std::endl;
+        if (closes_csv && opt.ext && n_objects)
             std::cerr << "MIN targets: " << nz_min << ", MAX targets: " << nz_max << ", AVG targets: "
                       << (float)nz_sum / n_objects << "\n";
         mc_group_free_batches(grp);

@@ -1,5 +1,7 @@
 // Test harness for jn_cuclark_amd/host/input.hpp (no GPU needed):
 //   host_input load <file>        -> the input image (gzip inflated) on stdout
+//   host_input gzseg <file.gz> <segment bytes> [threads] -> the segments of whole records a gzip file is classified in (gzstream.hpp),
+//                                    concatenated on stdout; on stderr "segments <n> largest <bytes> bad_starts <n> bgzf_blocks <n, -1: not BGZF or one thread>"
 //   host_input pair <f1> <f2>     -> the joined mates on stdout
 //   host_input pairp <f1> <f2> <threads> -> the same join on several threads (pairs.hpp)
 //   host_input packm <f1> <f2> <k>   -> the mates packed straight from the two files (pack_mates), same output format as pack
@@ -9,6 +11,7 @@
 #include "../../jn_cuclark_amd/host/input.hpp"
 #include "../../jn_cuclark_amd/host/reads.hpp"
 #include "../../jn_cuclark_amd/host/pairs.hpp"
+#include "../../jn_cuclark_amd/host/gzstream.hpp"
 
 #include <cstdio>
 #include <iostream>
@@ -21,6 +24,29 @@ int main(int argc, char **argv)
         host::InputImage img;
         if (!img.load(argv[2], err)) { std::cerr << err << std::endl; return 2; }
         std::fwrite(img.data(), 1, img.size(), stdout);
+        return 0;
+    }
+    if ((argc == 4 || argc == 5) && std::string(argv[1]) == "gzseg") {
+        if (!host::GzSegments::is_gzip(argv[2])) { std::cerr << "not a gzip file" << std::endl; return 2; }
+        host::GzSegments G;
+        if (!G.open(argv[2], (size_t)std::strtoull(argv[3], nullptr, 10), err, argc == 5 ? atoi(argv[4]) : 1)) { std::cerr << err << std::endl; return 2; }
+        host::GzSegments::Segment s;
+        size_t n = 0, bad = 0, largest = 0;
+        uint8_t first = 0;
+        bool seen_last = false;
+        while (G.next(s, err)) {
+            if (seen_last) bad++;                              // nothing comes after the segment marked last
+            if (n == 0 && s.size) first = s.data[0];
+            if (s.size && (first == '>' || first == '@') && s.data[0] != first) bad++;       // every segment opens with a record
+            if (s.size && (first == '>' || first == '@') && !s.last && s.data[s.size - 1] != '\n') bad++;
+            std::fwrite(s.data, 1, s.size, stdout);
+            largest = std::max(largest, s.size);
+            seen_last = s.last;
+            n++;
+        }
+        if (!err.empty()) { std::cerr << err << std::endl; return 2; }
+        if (!seen_last) bad++;
+        std::cerr << "segments " << n << " largest " << largest << " bad_starts " << bad << " bgzf_blocks " << (G.bgzf() ? (long)G.bgzf_blocks() : -1L) << std::endl;
         return 0;
     }
     if (argc == 5 && std::string(argv[1]) == "packm") {       // mates packed straight from their two files (reads.hpp pack_mates)
@@ -195,6 +221,6 @@ int main(int argc, char **argv)
         return 0;
     }
 #endif
-    std::cerr << "usage: host_input load <file> | pair <f1> <f2> | pack <file> <k> <threads> | indexfuzz[_fasta] <cases>" << std::endl;
+    std::cerr << "usage: host_input load <file> | gzseg <file.gz> <bytes> | pair <f1> <f2> | pack <file> <k> <threads> | indexfuzz[_fasta] <cases>" << std::endl;
     return 1;
 }

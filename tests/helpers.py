@@ -49,3 +49,18 @@ def pack_with_oracle(oracle, text, k):
     ns, ne, sp, ep, ln = oracle.index_reads(text)
     rp, con = oracle.pack_reads(text, sp, ep, ln, k)
     return (ns, ne, sp, ep, ln), rp, con
+
+
+def bgzf_compress(data, block=65280, eof_block=True):
+    """BGZF as bgzip / htslib write it (SAM spec 4.1): gzip members of at most 64 KB of text, each with a "BC" extra
+    field that holds the member's length minus one, and an empty member at the end"""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_block else [])
+    for c in chunks:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = co.compress(c) + co.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d
+        out += struct.pack("<II", zlib.crc32(c), len(c))
+    return bytes(out)

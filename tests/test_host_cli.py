@@ -458,6 +458,96 @@ def test_streamed_ingest_equals_the_oracle(oracle, tmp_path, mode):
     assert "%d reads)" % len(seqs) in r.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fastq", "fastq_card", "fasta_70", "extended", "gives_up", "contig", "members", "bgzf", "truncated"])
+def test_gzip_files_are_classified_in_segments(oracle, tmp_path, mode):
+    """A gzip file is inflated by a thread of its own into segments of whole records and classified segment by
+    segment, the lines of a segment written behind those of the one before (host/gzstream.hpp, host/main.cc
+    run_gz_segments; MC_GZ_SEGMENT_BYTES cuts the 256 MB of a segment down to 60 KB here, so a 0.5-1.3 MB text is a
+    dozen segments or more).  The CSV must be the one the oracle gives for the whole text: FASTQ through the host's
+    indexer and through the card's (`fastq_card`), multi-line FASTA, the extended table (its MIN/MAX/AVG line adds up
+    over the segments); `gives_up`: 400 KB segments, long reads first, then many short ones -- inside the segment that holds
+    both the streamed plan gives up and that segment alone is done again by the plan that indexes it whole; `contig`: a record of 300 KB, five
+    segments long, makes its segment grow; `members`: three concatenated gzip members (cat a.gz b.gz, bgzip);
+    `bgzf`: bgzip's 64 KB blocks, inflated by the four -n threads at once;
+    `truncated`: the file stops inside a member -- the reads of the segments before that are in the CSV, the run says
+    so and fails (the whole-file path, which inflates everything first, classifies nothing: MC_GZ_WHOLE=1)."""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta, bgzf_compress
+    _build()
+    k, ht = 27, 57777779
+    genomes = synth.toy_genomes(4, 5000, seed=53, shared=500)
+    labels = ["Ecoli", "Saureus", "Bsub", "Paer"]
+    targets = _write_targets(tmp_path, genomes, labels, n_mask=False)
+    dbdir = tmp_path / "db"
+    dbdir.mkdir()
+    names, seqs = mixed_fasta(genomes, k, seed=19, n=3000)
+    args = ["-T", targets, "-D", str(dbdir), "-R", str(tmp_path / "res"), "-n", "4", "-b", "5", "--verbose"]
+    if mode == "gives_up":
+        rng = np.random.default_rng(6)
+        long_ones = [synth.codes_to_ascii(genomes[i % 4][:4000]) for i in range(40)]          # 320 KB of the first 400 KB segment
+        short_ones = [synth.codes_to_ascii(genomes[i % 4][int(s):int(s) + 40]) for i, s in enumerate(rng.integers(0, 4900, 12000))]
+        seqs = long_ones + short_ones + long_ones
+        names = [b"r%d" % i for i in range(len(seqs))]
+    if mode == "contig":
+        big = np.concatenate([genomes[i % 4] for i in range(60)])
+        seqs = seqs[:1000] + [synth.codes_to_ascii(big)] + seqs[1000:]
+        names = names[:1000] + [b"contig_of_300k"] + names[1000:]
+    if mode in ("fasta_70", "contig"):
+        text = synth.fasta_text(names, seqs, width=70)
+    else:
+        text = synth.fastq_text(names, seqs)
+    if mode == "members":
+        a, b = len(text) // 3, 2 * len(text) // 3            # member ends fall inside records
+        z = gzip.compress(text[:a]) + gzip.compress(text[a:b]) + gzip.compress(text[b:])
+    elif mode == "bgzf":
+        z = bgzf_compress(text, block=20000)
+        assert gzip.decompress(z) == text
+    else:
+        z = gzip.compress(text)
+    if mode == "truncated":
+        z = z[:len(z) * 2 // 3]
+    p = tmp_path / "reads.gz"
+    p.write_bytes(z)
+    args += ["-O", str(p)] + (["--extended"] if mode == "extended" else [])
+    env = {"MC_STREAM_MIN_BYTES": "1", "MC_GZ_SEGMENT_BYTES": "400000" if mode == "gives_up" else "60000",
+           "MC_GPU_INGEST": "1" if mode == "fastq_card" else "0"}
+    r = _run("cuCLARK-l", args, env=env)
+    base = str(dbdir / ("db_central_k27_t4_s%d_m0_light_4.tsk" % ht))
+    want, _ = _expected_csv(oracle, text, k, ht, base, ["NA"] + labels, paired=False, extended=mode == "extended")
+    got = open(str(tmp_path / "res.csv")).read()
+    if mode == "truncated":
+        assert r.returncode != 0 and "zlib: truncated gzip input" in r.stderr and "reads only" in r.stderr, r.stderr
+        n_lines = got.count("\n")
+        assert 500 < n_lines < len(seqs) and want.startswith(got)
+        os.remove(str(tmp_path / "res.csv"))
+        r = _run("cuCLARK-l", args, env=dict(env, MC_GZ_WHOLE="1"))
+        assert "zlib: truncated gzip input" in r.stderr and not os.path.exists(str(tmp_path / "res.csv")), r.stderr
+        return
+    assert r.returncode == 0, r.stderr
+    n_seg = int(r.stderr.split("gzip input classified in ")[1].split()[0])
+    assert n_seg >= (3 if mode == "gives_up" else 5 if mode == "contig" else 8), r.stderr
+    assert got == want
+    assert "%d reads)" % len(seqs) in r.stderr and r.stderr.count("Done.") == 1 and r.stderr.count("Writing") == 1
+    assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up"), r.stderr
+    assert ("classified on the card" in r.stderr) == (mode == "fastq_card"), r.stderr
+    assert ("BGZF: " in r.stderr) == (mode == "bgzf"), r.stderr
+    if mode == "bgzf":
+        assert int(r.stderr.split("BGZF: ")[1].split()[0]) == (len(text) + 19999) // 20000 + 1
+    if mode == "contig":
+        assert int(r.stderr.split("segment(s) of at most ")[1].split()[0]) > 300000
+    if mode == "extended":
+        # the closing statistics are those of the whole file: the run on the inflated text prints the same line
+        q = tmp_path / "reads.fq"
+        q.write_bytes(text)
+        r2 = _run("cuCLARK-l", args[:-3] + ["-O", str(q), "--extended"], env=env)
+        line = [l for l in r.stderr.split("\n") if l.startswith("MIN targets")]
+        assert r2.returncode == 0 and len(line) == 1 and line == [l for l in r2.stderr.split("\n") if l.startswith("MIN targets")]
+        assert open(str(tmp_path / "res.csv")).read() == want
+
+
 STAND_IN_SCRIPT = """#!/bin/sh
 # stand-in for the exec line of the reference's scripts/classify_metagenome.sh (:84-87 prepend the contents of
 # .settings, :155-159 exec ../bin/cuCLARK or, with --light, ../bin/cuCLARK-l with the caller's arguments)
@@ -687,6 +777,97 @@ def test_input_images_gzip_and_pairing(tmp_path):
     (tmp_path / "m4.fa").write_bytes(synth.fasta_text(ids, seqs))
     r = subprocess.run([exe, "pair", str(tmp_path / "m1.fq"), str(tmp_path / "m4.fa")], capture_output=True)
     assert r.returncode == 2 and b"different format" in r.stderr
+
+
+def test_gzip_segments_are_whole_records_and_add_up_to_the_text(tmp_path):
+    """host/gzstream.hpp on the CPU: whatever the segment size (64 bytes: every record a segment of its own, up to
+    one segment for the file), the segments of a gzip file concatenate to its text, every segment opens with a record
+    start and ends with a newline, the last one is marked; FASTQ whose quality lines start with '@', multi-line and
+    single-line FASTA, records many segments long, a text without a final newline, a text that is no read file (one
+    segment, for the indexer to refuse), one and three gzip members, BGZF blocks inflated side by side; truncated, corrupt
+    and empty input"""
+    import gzip
+    exe = _input_harness(tmp_path)
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def fq(n, long_at=()):
+        out = bytearray()
+        for i in range(n):
+            L = 40000 if i in long_at else int(rng.integers(30, 260))
+            q = (b"@" + b"I" * (L - 1)) if i % 3 == 0 else b"I" * L
+            out += b"@r%d x\n" % i + acgt[rng.integers(0, 4, L)].tobytes() + b"\n+\n" + q + b"\n"
+        return bytes(out)
+
+    def fa(n, width, long_at=()):
+        out = bytearray()
+        for i in range(n):
+            L = 50000 if i in long_at else int(rng.integers(30, 600))
+            seq = acgt[rng.integers(0, 4, L)].tobytes()
+            out += b">c%d y\n" % i
+            out += b"".join(seq[j:j + width] + b"\n" for j in range(0, L, width)) if width else seq + b"\n"
+        return bytes(out)
+
+    cases = {"fq": fq(3000, {5, 1500, 2999}), "fa70": fa(1500, 70, {0, 700}), "fa0": fa(1500, 0, {1499}),
+             "junk": b"hello world\n" * 5000, "no_final_newline": fq(100)[:-1]}
+    f = tmp_path / "x.gz"
+    for name, t in cases.items():
+        for seg in (64, 1000, 4096, 70000, 10 ** 7):
+            for members in (1, 3):
+                a, b = len(t) // 3, 2 * len(t) // 3
+                f.write_bytes(gzip.compress(t) if members == 1 else gzip.compress(t[:a]) + gzip.compress(t[a:b]) + gzip.compress(t[b:]))
+                r = subprocess.run([exe, "gzseg", str(f), str(seg)], capture_output=True, timeout=120)
+                assert r.returncode == 0, (name, seg, r.stderr)
+                assert r.stdout == t, (name, seg, members)
+                w = r.stderr.split()
+                n_seg, largest, bad = int(w[1]), int(w[3]), int(w[5])
+                assert bad == 0, (name, seg, r.stderr)
+                if name == "junk" or seg == 10 ** 7:
+                    assert n_seg == 1
+                elif seg <= 4096:
+                    assert n_seg > len(t) // (3 * max(seg, 700)), (name, seg, r.stderr)      # segments stay segment-sized after a long record
+    # BGZF: the blocks inflated by four threads (one thread: the plain inflater does it, member by member); blocks
+    # followed by a member that is no block, by trailing bytes; a damaged block, a file that stops inside a block
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import bgzf_compress
+    t = cases["fq"]
+    zb = bgzf_compress(t)
+    assert gzip.decompress(zb) == t
+    half = len(t) // 2
+    for name, z, blocks in (("bgzf", zb, (len(t) + 65279) // 65280 + 1), ("no_eof_block", bgzf_compress(t, eof_block=False), (len(t) + 65279) // 65280),
+                            ("small_blocks", bgzf_compress(t, block=1000), (len(t) + 999) // 1000 + 1),
+                            ("then_a_plain_member", bgzf_compress(t[:half], eof_block=False) + gzip.compress(t[half:]), (half + 65279) // 65280),
+                            ("trailing_bytes", zb + b"\0\0\0\0garbage", (len(t) + 65279) // 65280 + 1)):
+        f.write_bytes(z)
+        for seg in (64, 5000, 200000, 10 ** 8):
+            for threads in (1, 4):
+                r = subprocess.run([exe, "gzseg", str(f), str(seg), str(threads)], capture_output=True, timeout=120)
+                assert r.returncode == 0, (name, seg, threads, r.stderr)
+                assert r.stdout == t, (name, seg, threads)
+                w = r.stderr.split()
+                assert int(w[5]) == 0 and int(w[7]) == (blocks if threads == 4 else -1), (name, seg, threads, r.stderr)
+    dam = bytearray(zb)
+    dam[len(dam) // 2] ^= 0x41
+    f.write_bytes(bytes(dam))
+    r = subprocess.run([exe, "gzseg", str(f), "200000", "4"], capture_output=True)
+    assert r.returncode == 2 and b"corrupt gzip input (bgzf block" in r.stderr
+    f.write_bytes(zb[:len(zb) // 2])
+    r = subprocess.run([exe, "gzseg", str(f), "200000", "4"], capture_output=True)
+    assert r.returncode == 2 and b"truncated gzip input" in r.stderr
+    z = gzip.compress(cases["fq"])
+    f.write_bytes(z[:-200])
+    r = subprocess.run([exe, "gzseg", str(f), "4096"], capture_output=True)
+    assert r.returncode == 2 and b"truncated gzip input" in r.stderr
+    zz = bytearray(z)
+    zz[len(zz) // 2] ^= 0xFF
+    zz[len(zz) // 2 + 1] ^= 0x55
+    f.write_bytes(bytes(zz))
+    r = subprocess.run([exe, "gzseg", str(f), "4096"], capture_output=True)
+    assert r.returncode == 2 and b"gzip input" in r.stderr
+    f.write_bytes(gzip.compress(b""))
+    r = subprocess.run([exe, "gzseg", str(f), "4096"], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"" and b"segments 1 largest 0" in r.stderr
 
 
 def test_fast_g_format_matches_printf(tmp_path):
