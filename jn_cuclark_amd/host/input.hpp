@@ -3,7 +3,8 @@
 //  * plain FASTA/FASTQ: mmap, as the reference does (src/CuCLARK_hh.hh:1339-1352);
 //  * gzip (magic 1f 8b, also concatenated members): inflated in memory with zlib -- the reference leaves
 //    this to its wrapper, which copies the file and runs gunzip on the copy
-//    (scripts/classify_metagenome.sh:118-137);
+//    (scripts/classify_metagenome.sh:118-137); BGZF blocks by several threads at once (gzstream.hpp, which also
+//    holds the segment-by-segment path single files take);
 //  * paired FASTQ: the mates are joined in memory into the FASTA records ">id\nR1NR2" that the reference
 //    writes to a temporary "<file1>_ConcatenatedByCLARK.fa" first (mergePairedFiles, src/file.cc:205-268).
 #pragma once
@@ -12,6 +13,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include "gzstream.hpp"
 
 #include <algorithm>
 #include <cstdint>
@@ -33,8 +36,9 @@ public:
     size_t size() const { return size_; }
     bool gzipped() const { return gz_; }
 
-    // false + err on failure; an empty file is a failure (as in the reference's size check)
-    bool load(const char *path, std::string &err)
+    // false + err on failure; an empty file is a failure (as in the reference's size check).  threads: how many inflate a
+    // BGZF file's blocks.
+    bool load(const char *path, std::string &err, int threads = 1)
     {
         release();
         fd_ = open(path, O_RDONLY);
@@ -50,10 +54,13 @@ public:
         const uint8_t *m = static_cast<const uint8_t *>(map_);
         if (map_len_ >= 2 && m[0] == 0x1f && m[1] == 0x8b) {
             gz_ = true;
-            if (!inflate_all(m, map_len_, own_, err)) { release(); return false; }
+            bool blocks = false;
+            if (threads > 1 && !inflate_bgzf(m, map_len_, threads, raw_, size_, err, blocks)) { release(); return false; }
+            if (!blocks && !inflate_all(m, map_len_, own_, err)) { release(); return false; }
             munmap(map_, map_len_); map_ = nullptr;
             close(fd_); fd_ = -1;
-            data_ = own_.data(); size_ = own_.size();
+            if (blocks) data_ = raw_;
+            else { data_ = own_.data(); size_ = own_.size(); }
             if (size_ == 0) { err = std::string("Failed to open ") + path; return false; }
         } else {
             data_ = m; size_ = map_len_;
@@ -84,6 +91,31 @@ private:
         map_ = nullptr; fd_ = -1; map_len_ = 0; data_ = nullptr; size_ = 0; gz_ = false;
         std::vector<uint8_t>().swap(own_);
         std::free(raw_); raw_ = nullptr;
+    }
+
+    // A file of BGZF blocks from end to end (trailing bytes that are no gzip member aside): the text's size is the sum of the
+    // sizes the blocks carry, so it is inflated in place by `threads` threads.  blocks = false: not such a file, nothing done.
+    static bool inflate_bgzf(const uint8_t *src, size_t n, int threads, uint8_t *&out, size_t &out_n, std::string &err, bool &blocks)
+    {
+        blocks = false;
+        size_t pos = 0, total = 0, bl = 0, tl = 0;
+        while (pos < n && BgzfInflater::parse(src + pos, n - pos, bl, tl)) { total += tl; pos += bl; }
+        if (pos == 0 || (n - pos >= 2 && src[pos] == 0x1f && src[pos + 1] == 0x8b)) return true;      // other members: the plain inflater
+        uint8_t *text = static_cast<uint8_t *>(std::malloc(total ? total : 1));
+        if (!text) { err = "out of memory (gzip input)"; return false; }
+        BgzfInflater B;
+        B.init(src, n, threads);
+        size_t filled = 0;
+        bool eof = false, full = false;
+        while (!eof) {
+            size_t got = 0;
+            if (!B.read(text + filled, total - filled, got, eof, full, err)) { std::free(text); return false; }
+            filled += got;
+            if (full) { err = "zlib: corrupt gzip input (bgzf block sizes)"; std::free(text); return false; }      // (never: the sizes were summed above)
+        }
+        out = text; out_n = filled;
+        blocks = true;
+        return true;
     }
 
     static bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)

@@ -237,7 +237,7 @@ struct Classifier {
         if (db_cycles == 1 && !opt.dump && !getenv("MC_GZ_WHOLE") && GzSegments::is_gzip(objects)) { run_gz_segments(objects, result); return; }
         InputImage img;                 // mmap, or inflated in memory when the file is gzip (database cycles, --dump-batches)
         std::string ierr;
-        if (!img.load(objects, ierr)) { std::cerr << ierr << std::endl; return; }
+        if (!img.load(objects, ierr, (int)opt.cpu)) { std::cerr << ierr << std::endl; return; }
         run_image(img.data(), img.size(), result);
     }
 
@@ -295,7 +295,16 @@ struct Classifier {
         std::cerr << "Classifying: " << f1 << " + " << f2 << "\n";
         InputImage a, b, joined;
         std::string err;
-        if (!a.load(f1, err) || !b.load(f2, err)) { std::cerr << err << std::endl; std::exit(1); }
+        {
+            // the two files side by side (gzip mates: two inflating threads, or -n / 2 threads per file for BGZF)
+            std::string err2;
+            bool ok2 = true;
+            const int th = (int)std::max<size_t>(1, opt.cpu / 2);
+            std::thread second([&]() { ok2 = b.load(f2, err2, th); });
+            const bool ok1 = a.load(f1, err, th);
+            second.join();
+            if (!ok1 || !ok2) { std::cerr << (ok1 ? err2 : err) << std::endl; std::exit(1); }
+        }
         struct timeval t0;
         gettimeofday(&t0, nullptr);
         size_t stream_min = 8u << 20;

@@ -1,5 +1,5 @@
 // Test harness for jn_cuclark_amd/host/input.hpp (no GPU needed):
-//   host_input load <file>        -> the input image (gzip inflated) on stdout
+//   host_input load <file> [threads] -> the input image (gzip inflated; BGZF blocks on several threads) on stdout
 //   host_input gzseg <file.gz> <segment bytes> [threads] -> the segments of whole records a gzip file is classified in (gzstream.hpp),
 //                                    concatenated on stdout; on stderr "segments <n> largest <bytes> bad_starts <n> bgzf_blocks <n, -1: not BGZF or one thread>"
 //   host_input pair <f1> <f2>     -> the joined mates on stdout
@@ -20,9 +20,9 @@
 int main(int argc, char **argv)
 {
     std::string err;
-    if (argc == 3 && std::string(argv[1]) == "load") {
+    if ((argc == 3 || argc == 4) && std::string(argv[1]) == "load") {          // load <file> [threads]
         host::InputImage img;
-        if (!img.load(argv[2], err)) { std::cerr << err << std::endl; return 2; }
+        if (!img.load(argv[2], err, argc == 4 ? atoi(argv[3]) : 1)) { std::cerr << err << std::endl; return 2; }
         std::fwrite(img.data(), 1, img.size(), stdout);
         return 0;
     }

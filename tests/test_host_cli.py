@@ -332,7 +332,9 @@ def test_end_to_end_csv_is_byte_identical_to_oracle(oracle, tmp_path, mode):
         t1, t2 = synth.fastq_text([n + b"/1" for n in nm], m1), synth.fastq_text([n + b"/2" for n in nm], m2)
         if mode == "paired_gz":
             f1, f2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
-            f1.write_bytes(gzip.compress(t1))
+            from helpers import bgzf_compress
+            f1.write_bytes(bgzf_compress(t1, block=5000))          # BGZF: inflated by -n / 2 threads, next to file 2
+            args += ["-n", "4"]
             # two concatenated gzip members (what `cat a.gz b.gz` or bgzip produce)
             cut = t2.index(b"\n@", len(t2) // 2) + 1
             f2.write_bytes(gzip.compress(t2[:cut]) + gzip.compress(t2[cut:]))
@@ -754,9 +756,23 @@ def test_input_images_gzip_and_pairing(tmp_path):
     cut = len(fq) // 3
     gz2.write_bytes(gzip.compress(fq[:cut]) + gzip.compress(fq[cut:]))          # concatenated members
     bad.write_bytes(gzip.compress(fq)[:-200])                                    # truncated
-    for f in (plain, gz, gz2):
-        r = subprocess.run([exe, "load", str(f)], capture_output=True)
-        assert r.returncode == 0 and r.stdout == fq, f
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import bgzf_compress
+    bg, bg2, bg3 = (tmp_path / n for n in ("b.fq.gz", "b2.fq.gz", "b3.fq.gz"))
+    bg.write_bytes(bgzf_compress(fq, block=3000))
+    bg2.write_bytes(bgzf_compress(fq[:cut], block=3000, eof_block=False) + gzip.compress(fq[cut:]))      # blocks, then a plain member
+    bg3.write_bytes(bgzf_compress(fq, block=3000) + b"\0\0xyz")                                         # trailing bytes
+    for f in (plain, gz, gz2, bg, bg2, bg3):
+        for threads in ("1", "4"):                       # 4: BGZF blocks are inflated side by side
+            r = subprocess.run([exe, "load", str(f), threads], capture_output=True)
+            assert r.returncode == 0 and r.stdout == fq, (f, threads)
+    dam = bytearray(bgzf_compress(fq, block=3000))
+    dam[len(dam) // 2] ^= 0x41
+    bad.write_bytes(bytes(dam))
+    r = subprocess.run([exe, "load", str(bad), "4"], capture_output=True)
+    assert r.returncode == 2 and b"gzip" in r.stderr
+    bad.write_bytes(gzip.compress(fq)[:-200])
     r = subprocess.run([exe, "load", str(bad)], capture_output=True)
     assert r.returncode == 2 and b"gzip" in r.stderr
     r = subprocess.run([exe, "load", str(tmp_path / "missing.fq")], capture_output=True)
