@@ -532,8 +532,11 @@ def test_gzip_files_are_classified_in_segments(oracle, tmp_path, mode):
     n_seg = int(r.stderr.split("gzip input classified in ")[1].split()[0])
     assert n_seg >= (3 if mode == "gives_up" else 5 if mode == "contig" else 8), r.stderr
     assert got == want
-    assert "%d reads)" % len(seqs) in r.stderr and r.stderr.count("Done.") == 1 and r.stderr.count("Writing") == 1
-    assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up"), r.stderr
+    assert "%d reads)" % len(seqs) in r.stderr and r.stderr.count("Done.") == 1
+    # ("Writing results..." comes with the segment that opens the CSV: once, or twice when that very segment is done again;
+    #  the segment that holds the contig may give the streamed plan up too -- one range with the contig, the others with short reads)
+    assert r.stderr.count("Writing") == 1 or (mode == "gives_up" and r.stderr.count("Writing") == 2), r.stderr
+    assert ("streamed ingest given up" in r.stderr) == (mode == "gives_up") or mode == "contig", r.stderr
     assert ("classified on the card" in r.stderr) == (mode == "fastq_card"), r.stderr
     assert ("BGZF: " in r.stderr) == (mode == "bgzf"), r.stderr
     if mode == "bgzf":
