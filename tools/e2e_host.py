@@ -2,7 +2,8 @@
 """End-to-end timing of the host driver on a FASTQ file (run on the GPU box):
 generate n reads of 150 bp (half from toy genomes), build a light database through the
 driver itself, then time `bin/cuCLARK-l -O reads.fq` as the reference reports it
-(`Done in Xs (N reads/min, M reads)`, src/CuCLARK_hh.hh:1931-1939)."""
+(`Done in Xs (N reads/min, M reads)`, src/CuCLARK_hh.hh:1931-1939).
+e2e_host.py [reads] [threads] [workdir] [paired | gz | bgzf]"""
 import os
 import subprocess
 import sys
@@ -63,6 +64,36 @@ def main():
         rec2.tofile(f2)
         inputs = ["-P", f1, f2]
         print("paired: 2 x %.2f GB" % (os.path.getsize(f1) / 1e9), flush=True)
+    want_sha = None
+    if len(sys.argv) > 4 and sys.argv[4] in ("gz", "bgzf"):
+        # the same file gzipped (one member, zlib level 1) or as BGZF blocks (bgzip's layout): classified segment by segment
+        # (host/gzstream.hpp); the CSV must be the plain file's
+        import hashlib
+        import zlib
+        r = subprocess.run([exe, "-T", work + "/targets.txt", "-D", work + "/db", "-O", fq, "-R", work + "/res", "-n", threads, "-b", "32"],
+                           capture_output=True, text=True)
+        want_sha = hashlib.sha256(open(work + "/res.csv", "rb").read()).hexdigest()[:16]
+        os.remove(work + "/res.csv")
+        t0 = time.time()
+        raw = open(fq, "rb").read()
+        if sys.argv[4] == "gz":
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            z = co.compress(raw) + co.flush()
+        else:
+            import struct
+            out = bytearray()
+            for i in list(range(0, len(raw), 65280)) + [len(raw)]:
+                c = raw[i:i + 65280]
+                co = zlib.compressobj(1, zlib.DEFLATED, -15)
+                d = co.compress(c) + co.flush()
+                out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(d) + 25) + d
+                out += struct.pack("<II", zlib.crc32(c), len(c))
+            z = bytes(out)
+        fq = work + "/reads.fq.gz"
+        open(fq, "wb").write(z)
+        inputs = ["-O", fq]
+        print("%s: %.2f GB in %.1fs (plain run: rc=%d, csv %s)" % (sys.argv[4], len(z) / 1e9, time.time() - t0, r.returncode, want_sha), flush=True)
+        del raw, z
     for run in range(2):
         t0 = time.time()
         r = subprocess.run([exe, "-T", work + "/targets.txt", "-D", work + "/db"] + inputs + ["-R", work + "/res",
@@ -72,6 +103,12 @@ def main():
         print("run %d: rc=%d wall %.2fs  %s" % (run, r.returncode, dt, " | ".join(tail)), flush=True)
     lines = sum(1 for _ in open(work + "/res.csv"))
     print("csv lines:", lines)
+    if want_sha:
+        import hashlib
+        got = hashlib.sha256(open(work + "/res.csv", "rb").read()).hexdigest()[:16]
+        print("csv of the gzip run %s the plain run's (%s)" % ("EQUALS" if got == want_sha else "DIFFERS FROM", got))
+        if got != want_sha:
+            raise SystemExit(1)
 
 
 if __name__ == "__main__":
