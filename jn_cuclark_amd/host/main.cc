@@ -411,7 +411,7 @@ struct Classifier {
         // sizes guessed from the head of the file (10 % head room); the guess is checked against what the index
         // says (whole-file plan: the buffers are allocated again if it was too small; streamed: see above).
         size_t guess_reads = 0, guess_con = 0, guess_nbuf = 0;
-        bool dev_ingest = false;
+        bool dev_ingest = false, hybrid = false;       // dev_ingest: ranges go up as text (hybrid: only card_share percent of them)
         std::thread early_alloc;
         int early_rc = MC_OK;
         std::string early_err;
@@ -420,7 +420,12 @@ struct Classifier {
         // a dozen buffers keeps uploads, kernels and the formatting of earlier batches going side by side)
         size_t text_range = 48u << 20;
         if (const char *e = getenv("MC_TEXT_RANGE_MB")) { const long v = atol(e); if (v >= 1 && v <= 2048) text_range = (size_t)v << 20; }
-        const bool card_wanted = streamed && opt.gpu_ingest && map[0] == '@' && !mates && !opt.ext && !opt.dump && text_path;
+        // MC_CARD_SHARE (percent, with the card's ingest on): that share of the ranges goes up as text, the others are indexed and
+        // packed here -- the two ways through a batch are bound by different things (the link: 317 bytes a read; the host's cores: two
+        // passes over the text), so a file takes both at once
+        size_t card_share = 100;
+        if (const char *e = getenv("MC_CARD_SHARE")) { const long v = atol(e); if (v >= 0 && v <= 100) card_share = (size_t)v; }
+        const bool card_wanted = streamed && opt.gpu_ingest && card_share > 0 && map[0] == '@' && !mates && !opt.ext && !opt.dump && text_path;
         if (card_wanted) nbatch_g = std::max(nbatch_g, (nb + text_range - 1) / text_range);
         if (nb >= (8u << 20) || streamed) {
             ReadIndex H;
@@ -436,6 +441,7 @@ struct Classifier {
                 // (plain FASTQ, streamed, final rows only: the card cuts and packs the records -- its buffers are allocated below,
                 // once the byte ranges are known)
                 dev_ingest = card_wanted && guess_con <= 0xFFFFFFFFull;
+                hybrid = dev_ingest && card_share < 100 && nbatch_g >= 4;
                 if (guess_con <= 0xFFFFFFFFull && !dev_ingest)
                     early_alloc = std::thread([&]() {
                         early_rc = mc_group_alloc_batches(grp, (uint32_t)guess_nbuf, guess_reads, guess_con, want_rows ? 1 : 0);
@@ -485,6 +491,8 @@ struct Classifier {
                 for (size_t b = 0; b < nbatch; b++) max_text = std::max(max_text, cut[b + 1] - cut[b] + 16);
                 early_alloc = std::thread([&, max_text]() {
                     early_rc = mc_group_text_alloc(grp, (uint32_t)guess_nbuf, max_text, guess_reads, guess_con);
+                    if (early_rc == MC_OK && hybrid)
+                        early_rc = mc_group_alloc_batches(grp, (uint32_t)std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)), guess_reads, guess_con, 0);
                     if (early_rc != MC_OK) early_err = mc_last_error();
                 });
             }
@@ -529,6 +537,33 @@ struct Classifier {
             ts2 = now();
         }
 
+        // Which ring of buffers a batch goes through (the card's text buffers or the pinned sets of packed reads), which slot of
+        // it, and which batches use that slot before and after it: a batch is packed / uploaded once the one before it in its
+        // slot has been formatted.
+        const size_t NONE = (size_t)-1;
+        std::vector<uint8_t> on_card(nbatch, dev_ingest ? 1 : 0);
+        std::vector<uint32_t> slot_of(nbatch, 0);
+        std::vector<size_t> next_in_slot(nbatch, NONE), prev_in_slot(nbatch, NONE);
+        size_t ring_card = dev_ingest ? nbuf : 0, ring_host = dev_ingest ? 0 : nbuf;
+        if (hybrid) {
+            size_t n_card = 0;
+            for (size_t b = 0; b < nbatch; b++) { on_card[b] = (b + 1) * card_share / 100 != b * card_share / 100; n_card += on_card[b]; }
+            ring_card = std::min(n_card, nbuf);
+            ring_host = std::min(nbatch - n_card, std::max<size_t>(2, std::min<size_t>(opt.cpu, 8)));
+        }
+        {
+            std::vector<size_t> last_card(std::max<size_t>(ring_card, 1), NONE), last_host(std::max<size_t>(ring_host, 1), NONE);
+            size_t jc = 0, jh = 0;
+            for (size_t b = 0; b < nbatch; b++) {
+                std::vector<size_t> &last = on_card[b] ? last_card : last_host;
+                const size_t sl = on_card[b] ? jc++ % ring_card : jh++ % ring_host;
+                slot_of[b] = (uint32_t)sl;
+                prev_in_slot[b] = last[sl];
+                if (last[sl] != NONE) next_in_slot[last[sl]] = b;
+                last[sl] = b;
+            }
+        }
+
         const uint32_t flags = (last_cycle ? MC_F_FINAL : 0u) | (want_rows ? MC_F_ROWS : 0u) | (cyc && cyc->i ? MC_F_FOLLOWUP : 0u);
         const size_t rows_len = 2 * (size_t)MAXHITS + 2;
         if (cyc && cyc->i == 0) cyc->rows->assign(R.size() * rows_len, 0);
@@ -549,7 +584,7 @@ struct Classifier {
             std::string ierr;
             const size_t len = cut[b + 1] - cut[b];
             X.R = &X.own; X.text = map + cut[b]; X.r0 = 0;
-            if (dev_ingest) {          // the card will say where the records are
+            if (on_card[b]) {          // the card will say where the records are
                 { std::lock_guard<std::mutex> lk(done_mu); X.indexed = true; }
                 done_cv.notify_all();
                 return;
@@ -584,13 +619,13 @@ struct Classifier {
                 done_cv.wait(lk, [&]() { return gave_up || (X.indexed && buffers_ready); });
                 stop = gave_up;
             }
-            if (!stop && dev_ingest) {
+            if (!stop && on_card[b]) {
                 // the bytes go up from where the file is mapped, on the buffer's own queue: several tasks upload at once
                 const double t_a = now();
-                mc_check(mc_group_text_submit(grp, (uint32_t)(b % nbuf), map + cut[b], cut[b + 1] - cut[b]), "mc_group_text_submit");
+                mc_check(mc_group_text_submit(grp, slot_of[b], map + cut[b], cut[b + 1] - cut[b]), "mc_group_text_submit");
                 { std::lock_guard<std::mutex> lk(done_mu); t_submit += now() - t_a; }
             } else if (!stop) {
-                const uint32_t buf = (uint32_t)(b % nbuf);
+                const uint32_t buf = slot_of[b];
                 uint32_t *ptr; uint16_t *con;
                 mc_check(mc_group_batch_buffers(grp, buf, &ptr, &con, nullptr, nullptr), "mc_group_batch_buffers");
                 X.ncon = mates ? pack_mates(X.text, X.own, X.text2, X.own2, X.n, (unsigned)opt.k, ptr, con, (size_t)(map + nb - X.text),
@@ -611,25 +646,25 @@ struct Classifier {
         if (streamed) {
             // the first nbuf batches are indexed and packed by one task each; the ranges behind them are indexed
             // by whoever is free (their buffers are in use until an earlier batch has been formatted)
-            for (size_t b = 0; b < nbuf; b++) pool.run([&, b]() { index_batch(b); pack_batch(b); });
-            for (size_t b = nbuf; b < nbatch; b++) pool.run([&, b]() { index_batch(b); });
+            for (size_t b = 0; b < nbatch; b++) if (prev_in_slot[b] == NONE) pool.run([&, b]() { index_batch(b); pack_batch(b); });
+            for (size_t b = 0; b < nbatch; b++) if (prev_in_slot[b] != NONE) pool.run([&, b]() { index_batch(b); });
             early_alloc.join();
             t_alloc = now();
             if (early_rc != MC_OK) die(std::string(dev_ingest ? "mc_group_text_alloc: " : "mc_group_alloc_batches: ") + early_err);
             { std::lock_guard<std::mutex> lk(done_mu); buffers_ready = true; }
             done_cv.notify_all();
         } else {
-            for (size_t b = 0; b < nbuf; b++) enqueue_pack(b);
+            for (size_t b = 0; b < nbatch; b++) if (prev_in_slot[b] == NONE) enqueue_pack(b);
         }
 
         if (cyc && !last_cycle) {
             for (size_t b = 0; b < nbatch; b++) {
                 { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return B[b].submitted; }); }
                 uint16_t *rows_out = nullptr;
-                mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
-                mc_check(mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, nullptr, &rows_out), "mc_group_batch_buffers");
+                mc_check(mc_group_wait(grp, slot_of[b]), "mc_group_wait");
+                mc_check(mc_group_batch_buffers(grp, slot_of[b], nullptr, nullptr, nullptr, &rows_out), "mc_group_batch_buffers");
                 std::memcpy(cyc->rows->data() + B[b].r0 * rows_len, rows_out, B[b].n * rows_len * 2);
-                if (b + nbuf < nbatch) enqueue_pack(b + nbuf);
+                if (next_in_slot[b] != NONE) enqueue_pack(next_in_slot[b]);
             }
             pool.finish();
             std::fclose(fout);
@@ -788,13 +823,13 @@ struct Classifier {
                 if (gave_up) return false;
             }
             uint16_t *fin, *rows = nullptr;
-            if (dev_ingest) {
+            if (on_card[b]) {
                 uint64_t n_dev = 0; uint32_t status = 0;
                 uint32_t *hdr, *len;
                 const double t_a = now();
-                mc_check(mc_group_text_wait(grp, (uint32_t)(b % nbuf), &n_dev, &status), "mc_group_text_wait");
+                mc_check(mc_group_text_wait(grp, slot_of[b], &n_dev, &status), "mc_group_text_wait");
                 t_wait += now() - t_a;
-                mc_check(mc_group_text_buffers(grp, (uint32_t)(b % nbuf), &hdr, &len, &fin), "mc_group_text_buffers");
+                mc_check(mc_group_text_buffers(grp, slot_of[b], &hdr, &len, &fin), "mc_group_text_buffers");
                 if (status) {          // a batch the card does not vouch for: the whole file goes the host's way
                     std::lock_guard<std::mutex> lk(done_mu);
                     gave_up = true; dev_gave_up = true;
@@ -805,8 +840,8 @@ struct Classifier {
                 X.n = (size_t)n_dev; X.dev_hdr = hdr; X.dev_len = len;
                 X.own.name_s.resize(X.n); X.own.name_e.resize(X.n); X.own.len.resize(X.n);
             } else {
-                mc_check(mc_group_wait(grp, (uint32_t)(b % nbuf)), "mc_group_wait");
-                mc_group_batch_buffers(grp, (uint32_t)(b % nbuf), nullptr, nullptr, &fin, &rows);
+                mc_check(mc_group_wait(grp, slot_of[b]), "mc_group_wait");
+                mc_group_batch_buffers(grp, slot_of[b], nullptr, nullptr, &fin, &rows);
             }
             Formatted &F = fmt[b];
             F.slice.reset(new Text[nfmt]); F.s_min.assign(nfmt, 0); F.s_max.assign(nfmt, 0); F.s_sum.assign(nfmt, 0);
@@ -825,10 +860,11 @@ struct Classifier {
         size_t launched = 0;
         bool ok = launch_format(launched++);
         for (size_t b = 0; ok && b < nbatch; b++) {
-            while (ok && launched < nbatch && launched <= b + ahead && launched < b + nbuf) { if (!launch_format(launched)) ok = false; else launched++; }
+            // (a batch further on has been packed or uploaded only if the batch before it in its slot is through: < b)
+            while (ok && launched < nbatch && launched <= b + ahead && (prev_in_slot[launched] == NONE || prev_in_slot[launched] < b)) { if (!launch_format(launched)) ok = false; else launched++; }
             { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&]() { return fmt[b].left == 0; }); }
             if (!ok) break;
-            if (b + nbuf < nbatch) enqueue_pack(b + nbuf);      // this batch's buffers are free again
+            if (next_in_slot[b] != NONE) enqueue_pack(next_in_slot[b]);      // this batch's buffers are free again
             Formatted &F = fmt[b];
             const size_t nr = B[b].n;
             n_done += nr;
@@ -880,6 +916,7 @@ struct Classifier {
         if (opt.verbose) {
             if (streamed)
                 std::cerr << "timing: streamed (" << nbatch << (mates ? " byte ranges of both files" : " byte ranges")
+                          << (hybrid ? ", " + std::to_string(card_share) + " % of them as text to the card" : std::string())
                           << (dev_ingest ? ": copy+submit | records cut, packed and classified on the card | wait+format+write, all overlapped) "
                                          : ": index | pack+submit | wait+format+write, all overlapped) ")
                           << now() - ts0 << " s"

@@ -42,6 +42,9 @@ def main():
                     help="also: the same reads as mates of two files (-P r_1.fq r_2.fq; mate 2 = the same records again), "
                          "the driver's direct two-file ingest (no joined copy of the files)")
     ap.add_argument("--sweep", default="", help="threads:batches pairs to run after the two standard runs, e.g. 16:64,16:128,32:64")
+    ap.add_argument("--card-shares", default="",
+                    help="percentages, e.g. 0,40,60,100: after the standard runs, the same file with that share of its ranges going to the "
+                         "card as text (MC_GPU_INGEST / MC_CARD_SHARE: 0 = the host indexes and packs everything, 100 = the card does)")
     ap.add_argument("--load-times", action="store_true",
                     help="also time tools/load_time.py on the files: 1 member, 2 and 3 members (parts) on this card, with this "
                          "build and -- when build/libmcclark_r02.so is there -- with round 2's loader")
@@ -158,6 +161,17 @@ def run(a, out, dev, work):
         r = synth_gpu.host_driver_run(exe, work, K, T, fq, a.reads, threads=t_, batches=b_, truth=truth)
         print("sweep -n %d -b %d: %.2f Mreads/s, wall %.1f s | %s" % (t_, b_, r["Mreads_per_s"], r["wall_s"], " | ".join(r["timing"])), flush=True)
         out.setdefault("sweep", []).append({"threads": t_, "batches": b_, "Mreads_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"]})
+    for sh in [int(x) for x in a.card_shares.split(",") if x]:
+        os.environ["MC_GPU_INGEST"] = "1" if sh > 0 else "0"
+        os.environ["MC_CARD_SHARE"] = str(sh)
+        for rep in range(2):
+            r = synth_gpu.host_driver_run(exe, work, K, T, fq, a.reads, threads=a.threads, batches=a.batches, truth=truth)
+            assert r["csv_lines"] == a.reads and r["assigned_to_their_genome"] > 0.995 * r["checked"] and r["assigned_elsewhere"] < 200, r
+            size = os.path.getsize(os.path.join(work, "res.csv"))
+            print("card share %3d %% run %d: %.2f Mreads/s, wall %.1f s, csv %d bytes | %s" % (sh, rep, r["Mreads_per_s"], r["wall_s"], size, " | ".join(r["timing"])[:420]), flush=True)
+            out.setdefault("card_shares", []).append({"share": sh, "Mreads_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"], "csv_bytes": size})
+    os.environ.pop("MC_GPU_INGEST", None)
+    os.environ.pop("MC_CARD_SHARE", None)
     if a.paired:
         # mate files: the same records with /1 and /2 behind the id (the ids match after the cut at '/', src/file.cc:205-268)
         f1, f2 = os.path.join(work, "r_1.fq"), os.path.join(work, "r_2.fq")
