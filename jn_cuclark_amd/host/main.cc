@@ -740,7 +740,11 @@ struct Classifier {
             // confidence = best / (best + second): the text per (best, second) pair while both stay below 128
             // (a 150 bp read has at most 120-124 hits)
             static thread_local std::vector<std::array<char, 16>> memo2(128 * 128, std::array<char, 16>{});      // (the text depends on the pair only)
+            // the only bytes of a record this pass reads are its name: one cache line out of the five a 150 bp FASTQ record spans,
+            // long gone from the caches since the indexer ran over it -- asked for a few records ahead (MC_FMT_PREFETCH=0: not)
+            static const size_t pf_ahead = []() { const char *e = getenv("MC_FMT_PREFETCH"); return e ? (size_t)atol(e) : (size_t)12; }();
             for (size_t i = i0; i < i1; i++) {
+                if (pf_ahead && i + pf_ahead < i1) __builtin_prefetch(text + RI.name_s[i + pf_ahead], 0, 0);
                 const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
                 const uint32_t total = r5[0], ibest = r5[1], best = r5[2], s_best = r5[4];
                 size_t nl = RI.name_e[i] - RI.name_s[i];

@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--card-shares", default="",
                     help="percentages, e.g. 0,40,60,100: after the standard runs, the same file with that share of its ranges going to the "
                          "card as text (MC_GPU_INGEST / MC_CARD_SHARE: 0 = the host indexes and packs everything, 100 = the card does)")
+    ap.add_argument("--env-sweep", default="",
+                    help="A/B of switches of the host driver: settings separated by ';', each NAME=VALUE[,NAME=VALUE...]; every setting gets "
+                         "--env-reps runs after the standard ones, interleaved (e.g. MC_FMT_PREFETCH=0;MC_FMT_PREFETCH=12)")
+    ap.add_argument("--env-reps", type=int, default=3)
     ap.add_argument("--load-times", action="store_true",
                     help="also time tools/load_time.py on the files: 1 member, 2 and 3 members (parts) on this card, with this "
                          "build and -- when build/libmcclark_r02.so is there -- with round 2's loader")
@@ -172,6 +176,17 @@ def run(a, out, dev, work):
             out.setdefault("card_shares", []).append({"share": sh, "Mreads_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"], "csv_bytes": size})
     os.environ.pop("MC_GPU_INGEST", None)
     os.environ.pop("MC_CARD_SHARE", None)
+    settings = [x for x in a.env_sweep.split(";") if x]
+    for rep in range(a.env_reps if settings else 0):
+        for st in settings:
+            kv = dict(x.split("=", 1) for x in st.split(","))
+            os.environ.update(kv)
+            r = synth_gpu.host_driver_run(exe, work, K, T, fq, a.reads, threads=a.threads, batches=a.batches, truth=truth)
+            for k_ in kv:
+                os.environ.pop(k_, None)
+            assert r["csv_lines"] == a.reads and r["assigned_to_their_genome"] > 0.995 * r["checked"], r
+            print("env %-40s rep %d: %.2f Mreads/s, wall %.1f s | %s" % (st, rep, r["Mreads_per_s"], r["wall_s"], " | ".join(r["timing"])[:200]), flush=True)
+            out.setdefault("env_sweep", []).append({"env": st, "Mreads_per_s": r["Mreads_per_s"], "wall_s": r["wall_s"]})
     if a.paired:
         # mate files: the same records with /1 and /2 behind the id (the ids match after the cut at '/', src/file.cc:205-268)
         f1, f2 = os.path.join(work, "r_1.fq"), os.path.join(work, "r_2.fq")
