@@ -740,9 +740,12 @@ struct Classifier {
             // confidence = best / (best + second): the text per (best, second) pair while both stay below 128
             // (a 150 bp read has at most 120-124 hits)
             static thread_local std::vector<std::array<char, 16>> memo2(128 * 128, std::array<char, 16>{});      // (the text depends on the pair only)
-            // the only bytes of a record this pass reads are its name: one cache line out of the five a 150 bp FASTQ record spans,
-            // long gone from the caches since the indexer ran over it -- asked for a few records ahead (MC_FMT_PREFETCH=0: not)
-            static const size_t pf_ahead = []() { const char *e = getenv("MC_FMT_PREFETCH"); return e ? (size_t)atol(e) : (size_t)12; }();
+            // The only bytes of a record this pass reads are its name: one cache line out of the five a 150 bp FASTQ record spans, gone
+            // from the caches since the indexer ran over it.  MC_FMT_PREFETCH=<records> asks for it that many records ahead.  Off by
+            // default: file -> CSV at the metric's size, interleaved runs, said 62-65 M reads/s without and 75-80 with 32 ahead on one
+            // box, 64-83 without and 58-73 with 48 ahead on the next (profiles/r04_format_prefetch_ab.txt) -- the boxes' own spread
+            // is larger than whatever this buys.
+            static const size_t pf_ahead = []() { const char *e = getenv("MC_FMT_PREFETCH"); return e ? (size_t)atol(e) : (size_t)0; }();
             for (size_t i = i0; i < i1; i++) {
                 if (pf_ahead && i + pf_ahead < i1) __builtin_prefetch(text + RI.name_s[i + pf_ahead], 0, 0);
                 const uint16_t *r5 = fin + (i - r0) * MC_FINAL_ROW;
