@@ -47,6 +47,39 @@ def test_abundance_tables_equal_the_reference_tools(tmp_path, case):
             assert open(str(w / f)).read() == open(os.path.join(GOLD, "out_" + f)).read(), f
 
 
+def test_abundance_tools_are_clean_under_address_and_ub_sanitizers(tmp_path):
+    """host/getAbundance.cc and host/kent.cc built with -fsanitize=address,undefined (CPU build only): every golden table
+    again, the merge and the report of kent, the argument errors -- the same bytes, no sanitizer report"""
+    exes = {}
+    for name in ("getAbundance", "kent"):
+        exes[name] = str(tmp_path / (name + "_san"))
+        r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-fopenmp", "-pthread",
+                            "-o", exes[name], os.path.join(ROOT, "jn_cuclark_amd", "host", name + ".cc")], capture_output=True, text=True)
+        if r.returncode != 0 and "sanitize" in r.stderr.lower():
+            pytest.skip("no sanitizer runtime in this toolchain")
+        assert r.returncode == 0, r.stderr
+    w = _workdir(tmp_path)
+
+    def run(exe, args, rc=0):
+        q = subprocess.run([exes[exe]] + args, cwd=str(w), capture_output=True, text=True)
+        assert q.returncode == rc, (args, q.returncode, q.stderr[-500:])
+        assert "Sanitizer" not in q.stderr and "runtime error" not in q.stderr, (args, q.stderr[-900:])
+        return q
+
+    for case in sorted(CASES):
+        assert run("getAbundance", CASES[case]).stdout == open(os.path.join(GOLD, "out_%s.csv" % case)).read(), case
+    run("getAbundance", ["-c", "0.2", "-F", "result1.csv"], rc=1)
+    run("getAbundance", ["-F", "missing.csv", "x"], rc=1)
+    (w / "results").mkdir()
+    for a, b, out in (("out_taxonomy.csv", "out_highconf.csv", "merged_lineage.csv"), ("out_plain.csv", "out_two_files.csv", "merged_plain.csv")):
+        run("kent", ["-m", str(w / a), str(w / b), "-o", out])
+        assert open(str(w / "results" / out)).read() == open(os.path.join(GOLD, out)).read()
+    for src, out in (("out_taxonomy.csv", "report_taxonomy.txt"), ("merged_lineage.csv", "report_merged.txt")):
+        run("kent", ["-r", str(w / src)])
+        assert open(str(w / "results" / "report.txt")).read() == open(os.path.join(GOLD, out)).read()
+    run("kent", ["-m", str(w / "out_plain.csv")], rc=1)
+
+
 def test_abundance_argument_errors(tmp_path):
     _build()
     w = _workdir(tmp_path)

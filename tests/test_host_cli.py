@@ -899,6 +899,65 @@ def test_gzip_segments_are_whole_records_and_add_up_to_the_text(tmp_path):
     assert r.returncode == 0 and r.stdout == b"" and b"segments 1 largest 0" in r.stderr
 
 
+def test_host_input_code_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The host's text code (host/reads.hpp, simd.hpp, input.hpp, pairs.hpp, gzstream.hpp) built with
+    -fsanitize=address,undefined (CPU build only; the GPU pool has no sanitizer runs): both indexer fuzzers, index + pack
+    of FASTQ / multi-line FASTA on one and five threads, the sequential and the parallel mate join, mates packed from
+    two files, gzip segments of plain and BGZF files incl. the truncated and the damaged one -- no report, same exit codes"""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import mixed_fasta, bgzf_compress
+    exe = str(tmp_path / "host_input_san")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-fopenmp", "-pthread", "-o", exe,
+                        os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"], capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "ubsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("no sanitizer runtime in this toolchain: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+    def run(args, rc=0):
+        q = subprocess.run([exe] + [str(a) for a in args], capture_output=True, timeout=300, env=env)
+        assert q.returncode == rc, (args, q.returncode, q.stderr[-600:])
+        assert b"AddressSanitizer" not in q.stderr and b"LeakSanitizer" not in q.stderr and b"runtime error" not in q.stderr, (args, q.stderr[-900:])
+        return q
+
+    run(["indexfuzz", 8000])
+    run(["indexfuzz_fasta", 8000])
+    genomes = synth.toy_genomes(4, 9000, seed=78)
+    names, seqs = mixed_fasta(genomes, 27, seed=32, n=2500)
+    f = tmp_path / "r.txt"
+    for text in (synth.fastq_text(names, seqs), synth.fasta_text(names, seqs, width=70)):
+        f.write_bytes(text)
+        a = run(["pack", f, 27, 1]).stdout
+        assert a == run(["pack", f, 27, 5]).stdout and len(a) > 50000
+    ids = [b"r%d" % i for i in range(len(seqs))]
+    clean = [s.replace(b"\n", b"") for s in seqs]
+    m1, m2 = tmp_path / "m1.fq", tmp_path / "m2.fq"
+    m1.write_bytes(synth.fastq_text([i + b"/1" for i in ids], [s[:100] for s in clean]))
+    m2.write_bytes(synth.fastq_text([i + b"/2" for i in ids], [s[-80:] for s in clean]))
+    assert run(["pair", m1, m2]).stdout == run(["pairp", m1, m2, 5]).stdout
+    run(["packm", m1, m2, 27])
+    run(["mates", m1, m2, 7, 262144])
+    fq = synth.fastq_text(names, seqs)
+    z = tmp_path / "x.gz"
+    for blob in (gzip.compress(fq), gzip.compress(fq[:9999]) + gzip.compress(fq[9999:]), bgzf_compress(fq, block=3000),
+                 bgzf_compress(fq[:9999], block=3000, eof_block=False) + gzip.compress(fq[9999:])):
+        z.write_bytes(blob)
+        for seg in (64, 5000, 10 ** 7):
+            for threads in (1, 4):
+                assert run(["gzseg", z, seg, threads]).stdout == fq
+        assert run(["load", z, 4]).stdout == fq
+    z.write_bytes(bgzf_compress(fq, block=3000)[:-500])
+    run(["gzseg", z, 5000, 4], rc=2)
+    run(["load", z, 4], rc=2)
+    dam = bytearray(bgzf_compress(fq, block=3000))
+    dam[len(dam) // 2] ^= 0x41
+    z.write_bytes(bytes(dam))
+    run(["gzseg", z, 5000, 4], rc=2)
+    run(["load", z, 4], rc=2)
+
+
 def test_fast_g_format_matches_printf(tmp_path):
     """host/format.hpp: the CSV writer's printf-free "%g" of a ratio agrees with snprintf for every
     a <= b <= 2000 and a million random pairs up to 2^20, and declines what it does not cover"""
