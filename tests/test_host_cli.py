@@ -958,6 +958,43 @@ def test_host_input_code_is_clean_under_address_and_ub_sanitizers(tmp_path):
     run(["load", z, 4], rc=2)
 
 
+def test_threaded_input_code_is_clean_under_the_thread_sanitizer(tmp_path):
+    """-fsanitize=thread over the parts of the host's input code that run on std::thread: the gzip segmenter (a producer
+    thread, the consumer, and four threads inflating BGZF blocks), the whole-file BGZF inflater and the parallel mate join
+    (the OpenMP loops are left out: libgomp is not instrumented and reports races that are not there)"""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import bgzf_compress
+    exe = str(tmp_path / "host_input_tsan")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-fopenmp", "-pthread", "-o", exe,
+                        os.path.join(ROOT, "tests", "harness", "host_input.cc"), "-lz"], capture_output=True, text=True)
+    if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("no thread sanitizer runtime in this toolchain: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(2)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    t = b"".join(b"@r%d/1\n" % i + acgt[rng.integers(0, 4, 150)].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(20000))
+
+    def run(args, rc=0):
+        q = subprocess.run([exe] + [str(a) for a in args], capture_output=True, timeout=300)
+        if b"FATAL: ThreadSanitizer" in q.stderr:          # (the runtime could not set itself up in this container: nothing learnt)
+            pytest.skip("thread sanitizer runtime does not start here: " + q.stderr[-200:].decode(errors="replace"))
+        assert q.returncode == rc and b"ThreadSanitizer" not in q.stderr, (args, q.returncode, q.stderr[-900:])
+        return q
+
+    z = tmp_path / "t.gz"
+    for blob in (bgzf_compress(t), gzip.compress(t)):
+        z.write_bytes(blob)
+        for seg in (5000, 2000000):
+            assert run(["gzseg", z, seg, 4]).stdout == t
+        assert run(["load", z, 4]).stdout == t
+    f1, f2 = tmp_path / "p1.fq", tmp_path / "p2.fq"
+    f1.write_bytes(t)
+    f2.write_bytes(t.replace(b"/1\n", b"/2\n"))
+    assert run(["pairp", f1, f2, 5]).stdout.count(b">") == 20000
+
+
 def test_fast_g_format_matches_printf(tmp_path):
     """host/format.hpp: the CSV writer's printf-free "%g" of a ratio agrees with snprintf for every
     a <= b <= 2000 and a million random pairs up to 2^20, and declines what it does not cover"""
