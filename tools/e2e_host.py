@@ -52,7 +52,7 @@ def main():
     fq = work + "/reads.fq"
     rec.tofile(fq)
     print("generated %d reads (%.2f GB) in %.1fs" % (n, os.path.getsize(fq) / 1e9, time.time() - t0), flush=True)
-    exe = os.path.join(ROOT, "bin", "cuCLARK-l")
+    exe = os.environ.get("MC_E2E_EXE") or os.path.join(ROOT, "bin", "cuCLARK-l")          # (MC_E2E_EXE: another build of the driver, e.g. one with -fsanitize=thread)
     inputs = ["-O", fq]
     if len(sys.argv) > 4 and sys.argv[4] == "paired":
         # the same reads as mates: file 2 = the same records with "/2" names (ids match after the cut at '/')
