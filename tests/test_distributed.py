@@ -1,5 +1,5 @@
 """CPU suite, part 4: the N>1 path (DB sharded by bucket range, reduce-scatter of sparse
-rows by read range, merge, top-2) with world_size 2 and 3 on gloo."""
+rows by read range, merge, top-2) with world_size 2, 3 and 8 on gloo; S parts x G groups with 4, 5 and 8 ranks."""
 import os
 import subprocess
 import sys
@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,n_reads,chunks", [(2, 501, 4), (3, 200, 3), (2, 1, 4), (2, 7, 1)])
+@pytest.mark.parametrize("world,n_reads,chunks", [(2, 501, 4), (3, 200, 3), (2, 1, 4), (2, 7, 1), (8, 333, 3)])      # (8: the node's rank count, configs[3]/[4])
 def test_sharded_protocol_on_gloo(world, n_reads, chunks, tmp_path):
     out = str(tmp_path / "res.npz")
     port = 29600 + world * 7 + n_reads % 50 + chunks
@@ -25,7 +25,7 @@ def test_sharded_protocol_on_gloo(world, n_reads, chunks, tmp_path):
     assert np.array_equal(d["got"], d["want"])
 
 
-@pytest.mark.parametrize("world,shards", [(4, 2), (5, 2)])
+@pytest.mark.parametrize("world,shards", [(4, 2), (5, 2), (8, 2), (8, 4)])
 def test_shard_groups_on_gloo(world, shards, tmp_path):
     """S parts x G groups: a table that needs `shards` cards, `world` ranks -> world // shards groups that each hold
     the whole table and classify their own batch; a rank past the last full group stays idle (5 ranks, 2 parts)"""
@@ -41,7 +41,10 @@ def test_shard_groups_on_gloo(world, shards, tmp_path):
         d = np.load(out if g == 0 else out + ".g%d.npz" % g)
         assert d["got"].shape == (301, 5) and np.array_equal(d["got"], d["want"])
         seen.append(d["got"])
-    assert len(seen) == 2 and not np.array_equal(seen[0], seen[1])        # the groups worked on different batches
+    assert len(seen) == world // shards
+    for a in range(len(seen)):
+        for b in range(a + 1, len(seen)):
+            assert not np.array_equal(seen[a], seen[b])        # the groups worked on different batches
 
 
 def test_plan_shards():
