@@ -96,6 +96,16 @@ def load_library():
                 "%s is missing: build it with `make -C jn_cuclark_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                 "There is no CPU fallback." % path)
+        # One HIP runtime per process.  libmcclark.so needs "libamdhip64.so.7" (found in /opt/rocm through its RUNPATH); torch
+        # ships a copy of its own and asks for it by another name, so the loader shares torch's copy with us when torch came
+        # first, and loads BOTH when we came first -- and the runtime that starts second finds no device (seen on the GPU box:
+        # library loaded for mc_index_plan, then torch.cuda.is_available() True, then mc_open: "no HIP device visible";
+        # tools/probe/load_order.py).  This package uses torch for device memory and queues anyway: it goes first.  A program
+        # that binds the C ABI without torch (bin/cuCLARK, the reference's main.cc) has one runtime by construction.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)          # AttributeError if the export is missing
