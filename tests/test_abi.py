@@ -3,6 +3,8 @@ declares.  No compute calls: there is no GPU in the CPU test environment."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 
@@ -122,3 +124,21 @@ def test_index_plan_examples_of_the_review():
     huge = _lib.index_plan(40_000_000_000, 1, 4000 * 10**9)
     assert huge["fits"] == 1 and huge["fill"] > 9.0 and huge["lines_per_part"] < 0xFFFFFFF0
     assert _lib.index_plan(6_450_000_000, 1, CARD)["min_parts"] == 1
+
+
+def test_one_copy_of_the_hip_runtime_in_a_python_process():
+    """A fresh process that touches the package BEFORE it imports torch (mc_index_plan needs no device) and imports torch afterwards
+    maps ONE libamdhip64 -- torch's: jn_cuclark_amd._lib imports torch before it loads libmcclark.so.  The other order gave the process
+    /opt/rocm's copy next to torch's own, and on the GPU box the copy that started second found no device (mc_open: "no HIP device
+    visible", profiles/r04_two_hip_runtimes.txt).  The mapping can be checked without a card."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from jn_cuclark_amd import _lib\n"
+        "assert _lib.index_plan(6450000000, 1, 288 * 10**9)['fits'] == 1\n"
+        "import torch\n"
+        "copies = sorted({ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64' in ln})\n"
+        "print('\\n'.join(copies))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    copies = [c for c in r.stdout.strip().split("\n") if c]
+    assert len(copies) == 1 and os.sep + "torch" + os.sep in copies[0], copies
