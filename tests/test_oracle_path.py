@@ -208,3 +208,76 @@ def test_csv_line_format(oracle):
     assert oracle.csv_line(b"x" * 50, [0, 0, 0, 0, 0], 150, 31, "NA") == "x" * 39 + ",0,NA,0,0\n"
     # paired reads are normalised by length-1 (NBN), done by the caller
     assert oracle.csv_line(b"p", [120, 1, 120, 0, 0], 501 - 1, 31, "a").startswith("p,0.255319,a,120,1")
+
+
+def test_the_restatement_itself_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """oracle/clark_oracle.c is the checker of every GPU test: built with -fsanitize=address,undefined and driven through its
+    whole surface in a process of its own (the sanitizer runtimes preloaded into Python) -- indexer and packer on FASTQ and
+    multi-line FASTA with N runs, short reads, lower case and other symbols; table from arrays, written to files and read back;
+    lookups, sparse rows whole and in two bucket-range parts, merge, top-2, the discriminative-set builder -- no report, and the
+    same answers as the normal build gives in this process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "liboracle.so")
+    r = subprocess.run(["gcc", "-O1", "-g", "-fPIC", "-fopenmp", "-std=c11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-shared",
+                        "-o", so, os.path.join(root, "oracle", "clark_oracle.c")], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr.lower():
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr
+    pre = [subprocess.run(["gcc", "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(x) and os.path.exists(x) for x in pre):
+        pytest.skip("sanitizer runtimes not found as shared libraries: %r" % (pre,))
+    script = tmp_path / "drive.py"
+    script.write_text(
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from oracle import pyoracle\n"
+        "pyoracle._LIB_PATH = %r\n"
+        "pyoracle.build = lambda force=False: pyoracle._LIB_PATH\n"
+        "from jn_cuclark_amd import synth\n"
+        "from helpers import small_db, mixed_fasta\n"
+        "k, ht = %d, %d\n"
+        "genomes, sz, ky, lb = small_db(k=k, glen=6000)\n"
+        "names, seqs = mixed_fasta(genomes, k, n=3000)\n"
+        "out = []\n"
+        "for text in (synth.fastq_text(names, seqs), synth.fasta_text(names, seqs, width=70)):\n"
+        "    ns, ne, sp, ep, ln = pyoracle.index_reads(text)\n"
+        "    rp, con = pyoracle.pack_reads(text, sp, ep, ln, k)\n"
+        "    odb = pyoracle.OracleDB.from_arrays(ht, sz, ky, lb)\n"
+        "    fin, over = odb.classify(k, rp, con, 15)\n"
+        "    rows, _ = odb.query_rows(k, rp, con, 15)\n"
+        "    a, _ = odb.query_rows(k, rp, con, 15, part=(0, ht // 2))\n"
+        "    b, _ = odb.query_rows(k, rp, con, 15, part=(ht // 2, ht))\n"
+        "    m = pyoracle.merge_rows(a, b)\n"
+        "    assert np.array_equal(m, rows) and np.array_equal(pyoracle.result_rows(m), fin)\n"
+        "    odb.close()\n"
+        "    out.append(fin)\n"
+        "km = np.concatenate([synth.kmers_of(g, k) for g in genomes])\n"
+        "tg = np.concatenate([np.full(g.size - k + 1, i, dtype=np.uint16) for i, g in enumerate(genomes)])\n"
+        "canon, lab = pyoracle.build_discriminative(km, tg, k, ht)\n"
+        "base = sys.argv[1]\n"
+        "pyoracle.db_write(base, ht, 4, canon, lab)\n"
+        "db = pyoracle.OracleDB.load(base, ht, 4)\n"
+        "hits = sum(int(db.lookup(k, int(v))[0]) for v in km[:2000])\n"
+        "db.close()\n"
+        "np.savez(sys.argv[2], fq=out[0], fa=out[1], n=canon.size, hits=hits)\n"
+        "print('driven')\n" % (root, os.path.join(root, "tests"), so, K, HT))
+    env = dict(os.environ, LD_PRELOAD=":".join(pre), ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="4")
+    res = str(tmp_path / "res.npz")
+    q = subprocess.run([sys.executable, str(script), str(tmp_path / "db"), res], capture_output=True, text=True, timeout=600, env=env)
+    assert q.returncode == 0 and "driven" in q.stdout, q.stderr[-1500:]
+    assert "Sanitizer" not in q.stderr and "runtime error" not in q.stderr, q.stderr[-1500:]
+    # the same drive through the normal build, here
+    from oracle import pyoracle
+    genomes, sz, ky, lb = small_db(k=K, glen=6000)
+    names, seqs = mixed_fasta(genomes, K, n=3000)
+    d = np.load(res)
+    for key, text in (("fq", synth.fastq_text(names, seqs)), ("fa", synth.fasta_text(names, seqs, width=70))):
+        ns, ne, sp, ep, ln = pyoracle.index_reads(text)
+        rp, con = pyoracle.pack_reads(text, sp, ep, ln, K)
+        fin, _ = pyoracle.OracleDB.from_arrays(HT, sz, ky, lb).classify(K, rp, con, 15)
+        assert np.array_equal(fin, d[key]) and (fin[:, 2] > 0).sum() > 1000
+    assert int(d["n"]) > 1000 and int(d["hits"]) > 500
