@@ -24,3 +24,22 @@ def test_super_kmer_records_answer_like_a_set_of_canonical_kmers(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count(" 0 reads differ") == 14, r.stdout
+
+
+def test_the_same_under_address_and_ub_sanitizers(tmp_path):
+    """the host side of csrc/mc_skm.hpp (hash, entries, records, descriptors, match) compiled with -fsanitize=address,undefined
+    (host code only; the GPU pool runs no sanitizers): the same 14 cases, no report"""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc is not here")
+    exe = str(tmp_path / "skm_model_san")
+    r = subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "--offload-arch=gfx950", "-Xarch_host", "-fsanitize=address,undefined",
+                        "-Xarch_host", "-fno-omit-frame-pointer", "-x", "hip", os.path.join(ROOT, "tests", "cpu", "skm_model.cc"), "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr.lower():
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+    assert r.stdout.count(" 0 reads differ") == 14, r.stdout
