@@ -1003,6 +1003,14 @@ def test_fast_g_format_matches_printf(tmp_path):
     r = subprocess.run([exe, "2000", "1000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("checked ")
+    # and a smaller sweep of the same under the address / UB sanitizers
+    san = str(tmp_path / "host_format_san")
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-std=c++17", "-o", san, os.path.join(ROOT, "tests", "harness", "host_format.cc")],
+                       capture_output=True, text=True)
+    if b.returncode == 0:
+        r = subprocess.run([san, "600", "100000"], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("checked "), r.stderr[-800:]
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-800:]
 
 
 @pytest.mark.gpu
