@@ -101,6 +101,37 @@ def test_database_build_from_targets_matches_model(oracle, tmp_path, variant):
         assert r.returncode != 0 and "No HIP devices" in r.stderr      # no silent CPU fallback
 
 
+def test_the_driver_s_start_and_its_cpu_builder_are_clean_under_the_sanitizers(tmp_path):
+    """host/main.cc (-DMC_LIGHT) built with -fsanitize=address,undefined and run up to the point where it opens a device, with the
+    card hidden from it: command line, targets file, the CPU database builder (host/dbbuild.hpp: scan, sort, one-target rule, the
+    three files, the --tsk text files) -- no report, and the files are byte for byte those of the normal build"""
+    _build()
+    exe = str(tmp_path / "cuCLARK-l_san")
+    lib_dir = os.path.join(ROOT, "jn_cuclark_amd")
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17", "-fopenmp", "-pthread", "-DMC_LIGHT",
+                        "-o", exe, os.path.join(lib_dir, "host", "main.cc"), "-L" + lib_dir, "-lmcclark", "-lz", "-Wl,-rpath," + lib_dir],
+                       capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr.lower():
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert b.returncode == 0, b.stderr[-1500:]
+    genomes = synth.toy_genomes(5, 6000, seed=91, shared=700)
+    labels = ["A", "B", "B", "C", "D"]                     # two files of one target
+    targets = _write_targets(tmp_path, genomes, labels)
+    hidden = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    out = {}
+    for tag, prog in (("san", exe), ("plain", os.path.join(BIN, "cuCLARK-l"))):
+        d = tmp_path / ("db_" + tag)
+        d.mkdir()
+        r = subprocess.run([prog, "-T", targets, "-D", str(d) + "/", "-O", str(tmp_path / "genome0.fa"), "-R", str(tmp_path / ("res_" + tag)), "--tsk", "--verbose"],
+                           capture_output=True, text=True, timeout=900, env=hidden)
+        assert r.returncode != 0 and "No HIP devices" in r.stderr, r.stderr[-800:]          # (the build is done by then)
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-1500:]
+        out[tag] = {f: open(str(d / f), "rb").read() for f in sorted(os.listdir(str(d)))}
+    assert sorted(out["san"]) == sorted(out["plain"]) and len(out["san"]) >= 3 + 4          # .sz/.ky/.lb and one .ht per target
+    for f in out["plain"]:
+        assert out["san"][f] == out["plain"][f], f
+
+
 def test_mates_packed_from_two_files_equal_the_joined_records(tmp_path):
     """host/reads.hpp pack_mates (what the streamed plan of -P uses: no joined text) against the packer run on the
     joined records ">id\\nR1NR2" of the sequential join: mates with N, lower case, U, mates shorter than k, empty
