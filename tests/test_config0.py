@@ -33,6 +33,23 @@ def test_targets_definition_equals_the_reference_tools_output(tmp_path, rank):
     assert r.returncode == 1 and "Failed to recognize the rank" in r.stderr
 
 
+def test_targets_definition_tool_is_clean_under_the_sanitizers(tmp_path):
+    """host/getTargetsDef.cc with -fsanitize=address,undefined: both ranks and the refused rank, same bytes, no report"""
+    exe = str(tmp_path / "getTargetsDef_san")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-std=c++17", "-o", exe,
+                        os.path.join(root, "jn_cuclark_amd", "host", "getTargetsDef.cc")], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr.lower():
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert b.returncode == 0, b.stderr
+    for rank in (0, 1):
+        r = subprocess.run([exe, os.path.join(GOLD, "custom.fileToTaxIDs"), str(rank)], cwd=str(tmp_path), capture_output=True, text=True)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+        assert r.stdout == open(os.path.join(GOLD, "targets_rank%d.txt" % rank)).read()
+    r = subprocess.run([exe, os.path.join(GOLD, "custom.fileToTaxIDs"), "6"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 1 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
 def config0_genomes():
     """3 genomes x 100 000 nt uniform ACGT (seeds 1, 2, 3); genome 1 carries a 5 000-nt block of
     genome 0 (non-discriminative region)"""
